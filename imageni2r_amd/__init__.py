@@ -1,0 +1,16 @@
+"""imageni2r_amd -- MI355X (gfx950) native masked-diffusion hot path of ImagenI2R.
+
+Drop-in classes (same names / signatures / state-dict keys as the reference's models/*.py):
+    TS2img_Karras, EDMPrecond, DhariwalUNet, UNetBlock, Conv2d, GroupNorm, Linear, PositionalEmbedding,
+    DelayEmbedder, DiffusionProcess, LitEma
+All arithmetic runs in libi2r_hip.so (imageni2r_amd/csrc, C ABI in include/i2r_hip.h); importing this package does not
+need a GPU, calling an op does (there is no CPU fallback).
+"""
+from .networks import (Conv2d, DhariwalUNet, EDMPrecond, GroupNorm, Linear, PositionalEmbedding, UNetBlock)
+from .delay import DelayEmbedder
+from .ema import LitEma
+from .karras import TS2img_Karras
+from .sampler import DiffusionProcess
+
+__all__ = ["TS2img_Karras", "EDMPrecond", "DhariwalUNet", "UNetBlock", "Conv2d", "GroupNorm", "Linear",
+           "PositionalEmbedding", "DelayEmbedder", "DiffusionProcess", "LitEma"]

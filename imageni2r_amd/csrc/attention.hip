@@ -1,0 +1,419 @@
+// Low-resolution self-attention of the ADM UNet (models/networks.py:113-126, 181-184), fp32, head dim 64.
+// Input is the qkv 1x1-conv output (B, 3C, T) whose channels are interleaved (head, d, {q,k,v}) exactly as the
+// reference's reshape(B*h, C/h, 3, T).unbind(2) reads them; output is a (B, C, T) with channel = head*64 + c.
+//
+// T >= 64 (multiple of 32): flash-style kernel on the fp32 MFMA (v_mfma_f32_32x32x2_f32).  One wave owns 32 queries.
+//   S^T = K^T Q is computed with the QUERY on the MFMA column (= lane): a lane's 16 accumulator registers are 16 of
+//   the 32 keys of its own query, its partner lane (l ^ 32) holds the other 16 -> the softmax row reduction is 15
+//   in-register ops + one cross-half shuffle, and the per-query rescale of O is a per-lane scalar.
+//   P (registers) is fed straight back as the B operand of O += V P: the product reduces over the accumulator's row
+//   index, so the k-order of that MFMA chain is simply permuted to the order the rows sit in the registers
+//   (key(kk, h) = 4h + (kk & 3) + 8 (kk >> 2)) and V is read from LDS in the same order.  The T x T score matrix the
+//   reference materialises (268 MB per block at T = 1024, B = 32) never exists.
+// T <= 32: one 64-thread block per (sample, head) entirely in LDS.
+#include "i2r_common.h"
+#include "../../include/i2r_hip.h"
+
+#define HD 64          // head dim (channels_per_head, networks.py:393)
+#define KT 32          // keys per tile
+#define VLD (KT + 1)   // padded row of the V / K^T images read with the channel on the lane
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           float* __restrict__ lse, int heads, int T) {
+  __shared__ float Ks[HD * KT];
+  __shared__ float Vs[HD * VLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;  // row (d, s) at base + (3 d + s) T
+  const int q0 = (blockIdx.x * QW + wave) * 32;
+
+  float qf[HD / 2];
+#pragma unroll
+  for (int kk = 0; kk < HD / 2; ++kk) qf[kk] = base[(long)(3 * (2 * kk + h) + 0) * T + q0 + l31] * 0.125f;
+
+  f32x16 O[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[t][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  for (int k0 = 0; k0 < T; k0 += KT) {
+    __syncthreads();
+    for (int idx = tid; idx < HD * KT; idx += 64 * QW) {
+      int d = idx >> 5, key = idx & 31;
+      Ks[d * KT + key] = base[(long)(3 * d + 1) * T + k0 + key];
+      Vs[d * VLD + key] = base[(long)(3 * d + 2) * T + k0 + key];
+    }
+    __syncthreads();
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < HD / 2; ++kk)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * kk + h) * KT + l31], qf[kk], s, 0, 0, 0);
+    float mt = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float m_new = fmaxf(m_run, mt);
+    float alpha = expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      int key = 4 * h + (kk & 3) + 8 * (kk >> 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(t * 32 + l31) * VLD + key], s[kk], O[t], 0, 0, 0);
+    }
+  }
+  float inv_l = 1.0f / l_run;
+  float* ob = out + ((long)b * C + (long)hd * HD) * T;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      ob[(long)c * T + q0 + l31] = O[t][r] * inv_l;
+    }
+  if (lse && h == 0) lse[(long)bh * T + q0 + l31] = m_run + logf(l_run);
+}
+
+// T <= 32: everything in LDS, 64 threads per (sample, head)
+__global__ __launch_bounds__(64) void attn_fwd_small_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            float* __restrict__ lse, int heads, int T) {
+  __shared__ float Q[HD * 32], K[HD * 32], V[HD * 32], S[32 * 33];
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  for (int idx = tid; idx < HD * T; idx += 64) {
+    int d = idx / T, t = idx % T;
+    Q[d * 32 + t] = base[(long)(3 * d + 0) * T + t];
+    K[d * 32 + t] = base[(long)(3 * d + 1) * T + t];
+    V[d * 32 + t] = base[(long)(3 * d + 2) * T + t];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * T; idx += 64) {
+    int qi = idx / T, ki = idx % T;
+    float acc = 0.0f;
+    for (int d = 0; d < HD; ++d) acc += Q[d * 32 + qi] * (K[d * 32 + ki] * 0.125f);
+    S[qi * 33 + ki] = acc;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float m = S[tid * 33];
+    for (int k = 1; k < T; ++k) m = fmaxf(m, S[tid * 33 + k]);
+    float sum = 0.0f;
+    for (int k = 0; k < T; ++k) {
+      float e = expf(S[tid * 33 + k] - m);
+      S[tid * 33 + k] = e;
+      sum += e;
+    }
+    float inv = 1.0f / sum;
+    for (int k = 0; k < T; ++k) S[tid * 33 + k] *= inv;
+    if (lse) lse[(long)bh * T + tid] = m + logf(sum);
+  }
+  __syncthreads();
+  float* ob = out + ((long)b * C + (long)hd * HD) * T;
+  for (int qi = 0; qi < T; ++qi) {
+    float acc = 0.0f;
+    for (int k = 0; k < T; ++k) acc += S[qi * 33 + k] * V[tid * 32 + k];
+    ob[(long)tid * T + qi] = acc;
+  }
+}
+
+extern "C" int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T,
+                                     i2r_stream_t stream) {
+  I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (T <= 32) {
+    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
+  } else {
+    I2R_REQUIRE(T % 32 == 0, "attention_fwd: T=%d must be <= 32 or a multiple of 32", T);
+    if (T % 128 == 0)
+      hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(T / 128, B * heads), dim3(256), 0, s, qkv, out, lse, heads, T);
+    else if (T % 64 == 0)
+      hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(T / 64, B * heads), dim3(128), 0, s, qkv, out, lse, heads, T);
+    else
+      hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(T / 32, B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
+  }
+  return i2r_check_launch("attention_fwd");
+}
+
+// --------------------------------------------------------------------------------------------------- backward
+// AttentionOp.backward (networks.py:121-126) + the backward of einsum('nqk,nck->ncq', w, v) (:184), flash-style: the
+// probabilities are recomputed from q, k and the forward's log-sum-exp instead of being saved.
+//   delta[q] = sum_c da[c][q] a[c][q];  P = exp(S - lse);  dP[q][k] = sum_c da[c][q] v[c][k];  dS = P (dP - delta)
+//   dv[c][k] = sum_q da[c][q] P[q][k];  dq[d][q] = sum_k dS[q][k] k[d][k] / 8;  dk[d][k] = sum_q dS[q][k] q[d][q] / 8
+// Two deterministic kernels (no atomics): one owns 32 KEYS per wave and produces dk, dv; one owns 32 QUERIES per wave
+// and produces dq.  In each, the MFMA whose result feeds the next product is oriented so that the next product
+// reduces over its accumulator ROW index (registers) -- no cross-lane movement between the chained MFMAs.
+#define QLD 33
+
+__global__ void attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                  float* __restrict__ delta, int heads, int T, long total) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int q = (int)(i % T);
+  long bh = i / T;
+  const float* a = out + bh * HD * T + q;  // (b*C + hd*64) * T == bh * 64 * T since C = heads*64
+  const float* da = dout + bh * HD * T + q;
+  float acc = 0.0f;
+  for (int c = 0; c < HD; ++c) acc += a[(long)c * T] * da[(long)c * T];
+  delta[i] = acc;
+}
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               const float* __restrict__ dout,
+                                                               float* __restrict__ dqkv, int heads, int T) {
+  __shared__ float Qs[HD * QLD];
+  __shared__ float dAs[HD * QLD];
+  __shared__ float lse_s[32], del_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
+  const int key0 = (blockIdx.x * QW + wave) * 32;
+
+  float kf[HD / 2], vf[HD / 2];
+#pragma unroll
+  for (int kk = 0; kk < HD / 2; ++kk) {
+    kf[kk] = base[(long)(3 * (2 * kk + h) + 1) * T + key0 + l31] * 0.125f;
+    vf[kk] = base[(long)(3 * (2 * kk + h) + 2) * T + key0 + l31];
+  }
+  f32x16 dK[2], dV[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dK[t][r] = dV[t][r] = 0.0f;
+
+  for (int q0 = 0; q0 < T; q0 += 32) {
+    __syncthreads();
+    for (int idx = tid; idx < HD * 32; idx += 64 * QW) {
+      int d = idx >> 5, q = idx & 31;
+      Qs[d * QLD + q] = base[(long)(3 * d + 0) * T + q0 + q];
+      dAs[d * QLD + q] = dab[(long)d * T + q0 + q];
+    }
+    if (tid < 32) {
+      lse_s[tid] = lse[(long)bh * T + q0 + tid];
+      del_s[tid] = delta[(long)bh * T + q0 + tid];
+    }
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < HD / 2; ++kk) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(2 * kk + h) * QLD + l31], kf[kk], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dAs[(2 * kk + h) * QLD + l31], vf[kk], dp, 0, 0, 0);
+    }
+    // rows = query q(r,h), cols = key (lane)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int q = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float pr = expf(s[r] - lse_s[q]);
+      s[r] = pr;                          // P
+      dp[r] = pr * (dp[r] - del_s[q]);    // dS
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      int q = 4 * h + (kk & 3) + 8 * (kk >> 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        dV[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dAs[(t * 32 + l31) * QLD + q], s[kk], dV[t], 0, 0, 0);
+        dK[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(t * 32 + l31) * QLD + q], dp[kk], dK[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dbase[(long)(3 * d + 1) * T + key0 + l31] = dK[t][r] * 0.125f;
+      dbase[(long)(3 * d + 2) * T + key0 + l31] = dV[t][r];
+    }
+}
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(const float* __restrict__ qkv,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              const float* __restrict__ dout,
+                                                              float* __restrict__ dqkv, int heads, int T) {
+  __shared__ float Ks[HD * QLD];
+  __shared__ float Vs[HD * QLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
+  const int q0 = (blockIdx.x * QW + wave) * 32;
+
+  float qf[HD / 2], daf[HD / 2];
+#pragma unroll
+  for (int kk = 0; kk < HD / 2; ++kk) {
+    qf[kk] = base[(long)(3 * (2 * kk + h) + 0) * T + q0 + l31] * 0.125f;
+    daf[kk] = dab[(long)(2 * kk + h) * T + q0 + l31];
+  }
+  const float lse_q = lse[(long)bh * T + q0 + l31];
+  const float del_q = delta[(long)bh * T + q0 + l31];
+  f32x16 dQ[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[t][r] = 0.0f;
+
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    __syncthreads();
+    for (int idx = tid; idx < HD * 32; idx += 64 * QW) {
+      int d = idx >> 5, key = idx & 31;
+      Ks[d * QLD + key] = base[(long)(3 * d + 1) * T + k0 + key];
+      Vs[d * QLD + key] = base[(long)(3 * d + 2) * T + k0 + key];
+    }
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < HD / 2; ++kk) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * kk + h) * QLD + l31], qf[kk], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(2 * kk + h) * QLD + l31], daf[kk], dp, 0, 0, 0);
+    }
+    // rows = key(r,h), cols = query (lane)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = expf(s[r] - lse_q) * (dp[r] - del_q);  // dS^T
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      int key = 4 * h + (kk & 3) + 8 * (kk >> 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        dQ[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(t * 32 + l31) * QLD + key], dp[kk], dQ[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dbase[(long)(3 * d + 0) * T + q0 + l31] = dQ[t][r] * 0.125f;
+    }
+}
+
+// T <= 32: one 64-thread block per (sample, head), everything in LDS; recomputes the softmax itself.
+__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ dout,
+                                                            float* __restrict__ dqkv, int heads, int T) {
+  __shared__ float Q[HD * 32], K[HD * 32], V[HD * 32], dA[HD * 32], P[32 * 33], dS[32 * 33];
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
+  for (int idx = tid; idx < HD * T; idx += 64) {
+    int d = idx / T, t = idx % T;
+    Q[d * 32 + t] = base[(long)(3 * d + 0) * T + t];
+    K[d * 32 + t] = base[(long)(3 * d + 1) * T + t];
+    V[d * 32 + t] = base[(long)(3 * d + 2) * T + t];
+    dA[d * 32 + t] = dab[(long)d * T + t];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * T; idx += 64) {
+    int qi = idx / T, ki = idx % T;
+    float acc = 0.0f, dp = 0.0f;
+    for (int d = 0; d < HD; ++d) {
+      acc += Q[d * 32 + qi] * (K[d * 32 + ki] * 0.125f);
+      dp += dA[d * 32 + qi] * V[d * 32 + ki];
+    }
+    P[qi * 33 + ki] = acc;
+    dS[qi * 33 + ki] = dp;  // dP for now
+  }
+  __syncthreads();
+  if (tid < T) {
+    float m = P[tid * 33];
+    for (int k = 1; k < T; ++k) m = fmaxf(m, P[tid * 33 + k]);
+    float sum = 0.0f;
+    for (int k = 0; k < T; ++k) {
+      float e = expf(P[tid * 33 + k] - m);
+      P[tid * 33 + k] = e;
+      sum += e;
+    }
+    float inv = 1.0f / sum, del = 0.0f;
+    for (int k = 0; k < T; ++k) {
+      float pr = P[tid * 33 + k] * inv;
+      P[tid * 33 + k] = pr;
+      del += pr * dS[tid * 33 + k];
+    }
+    for (int k = 0; k < T; ++k) dS[tid * 33 + k] = P[tid * 33 + k] * (dS[tid * 33 + k] - del);
+  }
+  __syncthreads();
+  // thread = channel / head-dim index
+  for (int k = 0; k < T; ++k) {
+    float dv = 0.0f, dk = 0.0f;
+    for (int q = 0; q < T; ++q) {
+      dv += dA[tid * 32 + q] * P[q * 33 + k];
+      dk += dS[q * 33 + k] * Q[tid * 32 + q];
+    }
+    dbase[(long)(3 * tid + 1) * T + k] = dk * 0.125f;
+    dbase[(long)(3 * tid + 2) * T + k] = dv;
+  }
+  for (int q = 0; q < T; ++q) {
+    float dq = 0.0f;
+    for (int k = 0; k < T; ++k) dq += dS[q * 33 + k] * K[tid * 32 + k];
+    dbase[(long)(3 * tid + 0) * T + q] = dq * 0.125f;
+  }
+}
+
+extern "C" int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout,
+                                     float* dqkv, float* delta_ws, int B, int heads, int T, i2r_stream_t stream) {
+  I2R_REQUIRE(qkv && dout && dqkv && B > 0 && heads > 0 && T > 0, "attention_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (T <= 32) {
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(64), 0, s, qkv, dout, dqkv, heads, T);
+    return i2r_check_launch("attention_bwd");
+  }
+  I2R_REQUIRE(T % 32 == 0, "attention_bwd: T=%d must be <= 32 or a multiple of 32", T);
+  I2R_REQUIRE(out && lse && delta_ws, "attention_bwd: out, lse and delta workspace are required for T > 32");
+  long total = (long)B * heads * T;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(i2r_cdiv(total, 256)), dim3(256), 0, s, out, dout, delta_ws, heads, T,
+                     total);
+  if (T % 128 == 0) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3(T / 128, B * heads), dim3(256), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(T / 128, B * heads), dim3(256), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+  } else if (T % 64 == 0) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(T / 64, B * heads), dim3(128), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3(T / 64, B * heads), dim3(128), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(T / 32, B * heads), dim3(64), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, dim3(T / 32, B * heads), dim3(64), 0, s, qkv, lse, delta_ws, dout,
+                       dqkv, heads, T);
+  }
+  return i2r_check_launch("attention_bwd");
+}

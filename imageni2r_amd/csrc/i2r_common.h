@@ -1,0 +1,68 @@
+// Shared device/host helpers for libi2r_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define I2R_OK 0
+#define I2R_ERR_ARG -1
+#define I2R_ERR_HIP -2
+#define I2R_ERR_UNSUPPORTED -3
+
+void i2r_set_error(const char* fmt, ...);
+int i2r_check_launch(const char* what);
+
+#define I2R_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      i2r_set_error(__VA_ARGS__);         \
+      return I2R_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+
+static inline int i2r_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// wave64 all-reduce helpers (CDNA wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + expf(-u)); }
+// d silu(u) / du
+__device__ __forceinline__ float dsilu_f(float u) {
+  float s = 1.0f / (1.0f + expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+// Philox4x32-10 counter RNG (used for dropout keep-masks and training noise; regenerated, never stored)
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {  // (0,1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}

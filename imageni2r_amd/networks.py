@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's EDM network classes (models/networks.py), running on the HIP kernels.
+
+Same class names, constructor signatures, attribute names, parameter shapes and state-dict keys as the reference
+(Linear :30, Conv2d :49, GroupNorm :96, UNetBlock :134, PositionalEmbedding :193, DhariwalUNet :372, EDMPrecond :632),
+and parameters are drawn from torch's CPU generator in the same order with the same expressions, so
+``torch.manual_seed(s)`` gives bit-identical initial weights (checked against tests/golden/g2_init.json).
+Only the classes the ImagenI2R path instantiates are provided (models/our.py:26 -> EDMPrecond/DhariwalUNet).
+
+The forward methods only sequence kernels: every arithmetic step is an entry point of libi2r_hip.so (see ops.py).
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+import torch
+
+from . import ops
+
+_dropout_counter = itertools.count(1)
+
+
+def weight_init(shape, mode, fan_in, fan_out):
+    """Initialisers of networks.py:19-24 (same expressions => same bits for a given generator state)."""
+    if mode == 'xavier_uniform':
+        return np.sqrt(6 / (fan_in + fan_out)) * (torch.rand(*shape) * 2 - 1)
+    if mode == 'xavier_normal':
+        return np.sqrt(2 / (fan_in + fan_out)) * torch.randn(*shape)
+    if mode == 'kaiming_uniform':
+        return np.sqrt(3 / fan_in) * (torch.rand(*shape) * 2 - 1)
+    if mode == 'kaiming_normal':
+        return np.sqrt(1 / fan_in) * torch.randn(*shape)
+    raise ValueError(f'Invalid init mode "{mode}"')
+
+
+class Linear(torch.nn.Module):
+    def __init__(self, in_features, out_features, bias=True, init_mode='kaiming_normal', init_weight=1, init_bias=0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        kw = dict(mode=init_mode, fan_in=in_features, fan_out=out_features)
+        self.weight = torch.nn.Parameter(weight_init([out_features, in_features], **kw) * init_weight)
+        self.bias = torch.nn.Parameter(weight_init([out_features], **kw) * init_bias) if bias else None
+
+    def forward(self, x, act_silu=False):
+        """x @ W^T + b (:39-43); ``act_silu`` fuses the silu the UNet applies right after (:440, :447)."""
+        return ops.LinearFn.apply(x, self.weight, self.bias, act_silu)
+
+
+class Conv2d(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, kernel, bias=True, up=False, down=False, resample_filter=[1, 1],
+                 fused_resample=False, init_mode='kaiming_normal', init_weight=1, init_bias=0):
+        assert not (up and down)
+        super().__init__()
+        if fused_resample:
+            raise NotImplementedError("fused_resample is never used on the ImagenI2R path (DhariwalUNet)")
+        if list(resample_filter) != [1, 1]:
+            raise NotImplementedError("only the [1,1] box resample filter of DhariwalUNet is implemented")
+        if kernel not in (0, 1, 3):
+            raise NotImplementedError(f"kernel size {kernel}: the path uses 3x3, 1x1 and weight-less resampling only")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.up = up
+        self.down = down
+        self.fused_resample = fused_resample
+        kw = dict(mode=init_mode, fan_in=in_channels * kernel * kernel, fan_out=out_channels * kernel * kernel)
+        self.weight = torch.nn.Parameter(
+            weight_init([out_channels, in_channels, kernel, kernel], **kw) * init_weight) if kernel else None
+        self.bias = torch.nn.Parameter(weight_init([out_channels], **kw) * init_bias) if kernel and bias else None
+        f = torch.as_tensor(resample_filter, dtype=torch.float32)
+        f = f.ger(f).unsqueeze(0).unsqueeze(1) / f.sum().square()
+        self.register_buffer('resample_filter', f if up or down else None)  # kept for state-dict compatibility
+
+    def forward(self, x, residual=None):
+        """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue."""
+        if self.up:
+            x = ops.Up2Fn.apply(x)
+        if self.down:
+            x = ops.Down2Fn.apply(x)
+        if self.weight is not None:
+            return ops.Conv2dFn.apply(x, self.weight, self.bias, residual)
+        if residual is not None:
+            raise ValueError("residual needs a convolution to fuse into")
+        return x
+
+
+class GroupNorm(torch.nn.Module):
+    def __init__(self, num_channels, num_groups=32, min_channels_per_group=4, eps=1e-5):
+        super().__init__()
+        self.num_groups = min(num_groups, num_channels // min_channels_per_group)
+        self.eps = eps
+        self.weight = torch.nn.Parameter(torch.ones(num_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(num_channels))
+
+    def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0):
+        """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer."""
+        seed = offset = 0
+        if drop_p > 0.0:
+            seed, offset = torch.initial_seed() & ((1 << 63) - 1), next(_dropout_counter)
+        return ops.GroupNormFn.apply(x, self.weight, self.bias, scale_shift, self.num_groups, self.eps, act_silu,
+                                     drop_p, seed, offset)
+
+
+class UNetBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, emb_channels, up=False, down=False, attention=False,
+                 num_heads=None, channels_per_head=64, dropout=0, skip_scale=1, eps=1e-5, resample_filter=[1, 1],
+                 resample_proj=False, adaptive_scale=True, init=dict(), init_zero=dict(init_weight=0),
+                 init_attn=None):
+        super().__init__()
+        if not adaptive_scale or skip_scale != 1:
+            raise NotImplementedError("only the DhariwalUNet configuration (adaptive_scale, skip_scale=1) is built")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.emb_channels = emb_channels
+        self.num_heads = 0 if not attention else num_heads if num_heads is not None else out_channels // channels_per_head
+        self.dropout = dropout
+        self.skip_scale = skip_scale
+        self.adaptive_scale = adaptive_scale
+        if self.num_heads and out_channels != self.num_heads * 64:
+            raise NotImplementedError("attention head dim is fixed at 64 (channels_per_head=64, networks.py:393)")
+
+        self.norm0 = GroupNorm(num_channels=in_channels, eps=eps)
+        self.conv0 = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel=3, up=up, down=down,
+                            resample_filter=resample_filter, **init)
+        self.affine = Linear(in_features=emb_channels, out_features=out_channels * 2, **init)
+        self.norm1 = GroupNorm(num_channels=out_channels, eps=eps)
+        self.conv1 = Conv2d(in_channels=out_channels, out_channels=out_channels, kernel=3, **init_zero)
+        self.skip = None
+        if out_channels != in_channels or up or down:
+            kernel = 1 if resample_proj or out_channels != in_channels else 0
+            self.skip = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel=kernel, up=up, down=down,
+                               resample_filter=resample_filter, **init)
+        if self.num_heads:
+            self.norm2 = GroupNorm(num_channels=out_channels, eps=eps)
+            self.qkv = Conv2d(in_channels=out_channels, out_channels=out_channels * 3, kernel=1,
+                              **(init_attn if init_attn is not None else init))
+            self.proj = Conv2d(in_channels=out_channels, out_channels=out_channels, kernel=1, **init_zero)
+
+    def forward(self, x, emb):
+        """networks.py:166-187 as 6 (+4 with attention) kernels:
+        GN+SiLU -> conv0 -> affine -> GN+mod+SiLU(+dropout) -> [skip conv] -> conv1(+residual)
+        [-> GN -> qkv conv -> attention -> proj conv(+residual)]."""
+        orig = x
+        x = self.conv0(self.norm0(x, act_silu=True))
+        params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
+        x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0)
+        skip = self.skip(orig) if self.skip is not None else orig
+        x = self.conv1(x, residual=skip)
+        if self.num_heads:
+            qkv = self.qkv(self.norm2(x))
+            a = ops.AttentionFn.apply(qkv, self.num_heads)
+            x = self.proj(a, residual=x)
+        return x
+
+
+class PositionalEmbedding(torch.nn.Module):
+    def __init__(self, num_channels, max_positions=10000, endpoint=False):
+        super().__init__()
+        if endpoint:
+            raise NotImplementedError("endpoint=True is not used by DhariwalUNet")
+        self.num_channels = num_channels
+        self.max_positions = max_positions
+        self.endpoint = endpoint
+
+    def forward(self, x):
+        return ops.pos_embedding(x.to(torch.float32).reshape(-1).contiguous(), self.num_channels, self.max_positions)
+
+
+class DhariwalUNet(torch.nn.Module):
+    def __init__(self, img_resolution, in_channels, out_channels, label_dim=0, augment_dim=0, model_channels=192,
+                 channel_mult=[1, 2, 3, 4], channel_mult_emb=4, num_blocks=3, attn_resolutions=[32, 16, 8],
+                 dropout=0.10, label_dropout=0):
+        super().__init__()
+        if label_dim or augment_dim:
+            raise NotImplementedError("class / augment conditioning is not used by ImagenI2R (our.py:26-27)")
+        self.label_dropout = label_dropout
+        emb_channels = model_channels * channel_mult_emb
+        init = dict(init_mode='kaiming_uniform', init_weight=np.sqrt(1 / 3), init_bias=np.sqrt(1 / 3))
+        init_zero = dict(init_mode='kaiming_uniform', init_weight=0, init_bias=0)
+        block_kwargs = dict(emb_channels=emb_channels, channels_per_head=64, dropout=dropout, init=init,
+                            init_zero=init_zero)
+
+        self.map_noise = PositionalEmbedding(num_channels=model_channels)
+        self.map_augment = None
+        self.map_layer0 = Linear(in_features=model_channels, out_features=emb_channels, **init)
+        self.map_layer1 = Linear(in_features=emb_channels, out_features=emb_channels, **init)
+        self.map_label = None
+
+        self.enc = torch.nn.ModuleDict()
+        cout = in_channels
+        for level, mult in enumerate(channel_mult):
+            res = img_resolution >> level
+            if level == 0:
+                cin = cout
+                cout = model_channels * mult
+                self.enc[f'{res}x{res}_conv'] = Conv2d(in_channels=cin, out_channels=cout, kernel=3, **init)
+            else:
+                self.enc[f'{res}x{res}_down'] = UNetBlock(in_channels=cout, out_channels=cout, down=True,
+                                                          **block_kwargs)
+            for idx in range(num_blocks):
+                cin = cout
+                cout = model_channels * mult
+                self.enc[f'{res}x{res}_block{idx}'] = UNetBlock(in_channels=cin, out_channels=cout,
+                                                                attention=(res in attn_resolutions), **block_kwargs)
+        skips = [block.out_channels for block in self.enc.values()]
+
+        self.dec = torch.nn.ModuleDict()
+        for level, mult in reversed(list(enumerate(channel_mult))):
+            res = img_resolution >> level
+            if level == len(channel_mult) - 1:
+                self.dec[f'{res}x{res}_in0'] = UNetBlock(in_channels=cout, out_channels=cout, attention=True,
+                                                         **block_kwargs)
+                self.dec[f'{res}x{res}_in1'] = UNetBlock(in_channels=cout, out_channels=cout, **block_kwargs)
+            else:
+                self.dec[f'{res}x{res}_up'] = UNetBlock(in_channels=cout, out_channels=cout, up=True, **block_kwargs)
+            for idx in range(num_blocks + 1):
+                cin = cout + skips.pop()
+                cout = model_channels * mult
+                self.dec[f'{res}x{res}_block{idx}'] = UNetBlock(in_channels=cin, out_channels=cout,
+                                                                attention=(res in attn_resolutions), **block_kwargs)
+        self.out_norm = GroupNorm(num_channels=cout)
+        self.out_conv = Conv2d(in_channels=cout, out_channels=out_channels, kernel=3, **init_zero)
+
+    def embed(self, noise_labels):
+        """Noise-level embedding (:437-447): posemb -> Linear+SiLU -> Linear+SiLU."""
+        emb = self.map_noise(noise_labels)
+        emb = self.map_layer0(emb, act_silu=True)
+        return self.map_layer1(emb, act_silu=True)
+
+    def forward(self, x, noise_labels, class_labels=None, augment_labels=None):
+        emb = self.embed(noise_labels)
+        skips = []
+        for block in self.enc.values():
+            x = block(x, emb) if isinstance(block, UNetBlock) else block(x)
+            skips.append(x)
+        for block in self.dec.values():
+            if x.shape[1] != block.in_channels:
+                x = ops.ConcatFn.apply(x, skips.pop())
+            x = block(x, emb)
+        return self.out_conv(self.out_norm(x, act_silu=True))
+
+
+class EDMPrecond(torch.nn.Module):
+    def __init__(self, img_resolution, img_channels, label_dim=0, use_fp16=False, sigma_min=0,
+                 sigma_max=float('inf'), sigma_data=0.5, model_type='DhariwalUNet', **model_kwargs):
+        super().__init__()
+        if model_type != 'DhariwalUNet':
+            raise NotImplementedError("ImagenI2R only instantiates DhariwalUNet (our.py:26-27)")
+        if use_fp16:
+            raise NotImplementedError("use_fp16 is never set by ImagenI2R; the path is fp32")
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.label_dim = label_dim
+        self.use_fp16 = use_fp16
+        self.sigma_min = sigma_min
+        self.sigma_max = sigma_max
+        self.sigma_data = sigma_data
+        self.model = DhariwalUNet(img_resolution=img_resolution, in_channels=img_channels, out_channels=img_channels,
+                                  label_dim=label_dim, **model_kwargs)
+
+    def forward(self, x, sigma, class_labels=None, force_fp32=False, **model_kwargs):
+        """D = c_skip x + c_out F(c_in x, ln(sigma)/4) (:654-668).  x may be fp32 or fp64 (the sampler's state)."""
+        if not x.is_cuda:
+            raise ops._lib.I2RError("EDMPrecond.forward: input is on the CPU; the HIP path has no CPU fallback")
+        sigma = torch.as_tensor(sigma)
+        sig = ops._sigma_vec(sigma, x.device)
+        if sig.numel() not in (1, x.shape[0]):
+            raise ValueError("sigma must be a scalar or have one entry per sample")
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float32)
+        x = x if x.is_contiguous() else x.contiguous()
+        xin, c_noise = ops.edm_scale_input(x, sig, self.sigma_data)
+        F_x = self.model(xin, c_noise, class_labels=None, **model_kwargs)
+        return ops.EdmCombineFn.apply(x, F_x, sig, self.sigma_data)
+
+    def round_sigma(self, sigma):
+        return torch.as_tensor(sigma)

@@ -1,0 +1,507 @@
+"""Tensor-level wrappers over the C ABI (include/i2r_hip.h) and their torch.autograd.Function shells.
+
+PyTorch is used here for device memory, streams and the autograd tape only; every arithmetic step is a HIP kernel of
+libi2r_hip.so.  All wrappers validate on the host (device, dtype, contiguity, shapes) before a pointer is handed over.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.I2RError(f"{name}: tensor is on {t.device}; the HIP path needs a 'cuda' (HIP) tensor and there is "
+                            "no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ======================================================================================================= raw ops
+def ts_to_img(ts, delay, embedding, cols, side, pad_value=0.0, want_mask=False):
+    _chk(ts, "ts")
+    B, L, C = ts.shape
+    img = torch.empty((B, C, side, side), dtype=torch.float32, device=ts.device)
+    mask = torch.empty_like(img) if want_mask else None
+    _lib.call("i2r_ts_to_img_f32", _p(ts), _p(img), _p(mask), B, L, C, delay, embedding, cols, side, float(pad_value),
+              _stream())
+    return (img, mask) if want_mask else img
+
+
+def ts_to_img_bwd(dimg, L, delay, embedding, cols):
+    _chk(dimg, "dimg")
+    B, C, S, _ = dimg.shape
+    dts = torch.empty((B, L, C), dtype=torch.float32, device=dimg.device)
+    _lib.call("i2r_ts_to_img_bwd_f32", _p(dimg), _p(dts), B, L, C, delay, embedding, cols, S, _stream())
+    return dts
+
+
+def img_to_ts(img, L, delay, embedding, cols):
+    if img.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"img_to_ts: expected float32/float64, got {img.dtype}")
+    _chk(img, "img", img.dtype)
+    B, C, S, S2 = img.shape
+    if S != S2:
+        raise ValueError("img_to_ts: image must be square")
+    ts = torch.empty((B, L, C), dtype=torch.float32, device=img.device)
+    fn = "i2r_img_to_ts_f64" if img.dtype == torch.float64 else "i2r_img_to_ts_f32"
+    _lib.call(fn, _p(img), _p(ts), B, L, C, delay, embedding, cols, S, _stream())
+    return ts
+
+
+def conv2d_fwd(x, w, bias=None, residual=None):
+    _chk(x, "x"); _chk(w, "w")
+    B, Cin, H, W = x.shape
+    Cout, Cin2, k, k2 = w.shape
+    if Cin2 != Cin or k != k2:
+        raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    if bias is not None:
+        _chk(bias, "bias")
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != out.shape:
+            raise ValueError("conv2d: residual shape mismatch")
+    _lib.call("i2r_conv2d_fwd_f32", _p(x), _p(w), _p(bias), _p(residual), _p(out), B, Cin, H, W, Cout, k, _stream())
+    return out
+
+
+def conv2d_dgrad(dy, w):
+    _chk(dy, "dy"); _chk(w, "w")
+    B, Cout, H, W = dy.shape
+    Cout2, Cin, k, _ = w.shape
+    assert Cout2 == Cout
+    ws = torch.empty(w.numel(), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    _lib.call("i2r_conv2d_dgrad_f32", _p(dy), _p(w), _p(ws), _p(dx), B, Cin, H, W, Cout, k, _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, ksize, want_bias=True):
+    _chk(x, "x"); _chk(dy, "dy")
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    _lib.call("i2r_conv2d_wgrad_f32", _p(x), _p(dy), _p(dw), _p(db), B, Cin, H, W, Cout, ksize, _stream())
+    return dw, db
+
+
+def down2(x, scale=0.25):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_down2_f32", _p(x), _p(y), B * C, H, W, float(scale), _stream())
+    return y
+
+
+def up2(x, scale=1.0):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H * 2, W * 2), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_up2_f32", _p(x), _p(y), B * C, H, W, float(scale), _stream())
+    return y
+
+
+def concat_channels(a, c):
+    _chk(a, "a"); _chk(c, "c")
+    B, C1, H, W = a.shape
+    C2 = c.shape[1]
+    out = torch.empty((B, C1 + C2, H, W), dtype=torch.float32, device=a.device)
+    _lib.call("i2r_concat_channels_f32", _p(a), _p(c), _p(out), B, C1 * H * W, C2 * H * W, _stream())
+    return out
+
+
+def split_channels(x, C1):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    a = torch.empty((B, C1, H, W), dtype=torch.float32, device=x.device)
+    c = torch.empty((B, C - C1, H, W), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_split_channels_f32", _p(x), _p(a), _p(c), B, C1 * H * W, (C - C1) * H * W, 0, _stream())
+    return a, c
+
+
+def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=False, drop_p=0.0, seed=0, offset=0):
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    ss_batch = 0
+    if ss is not None:
+        _chk(ss, "scale_shift")
+        if ss.shape[-1] != 2 * C:
+            raise ValueError("groupnorm: scale/shift must have 2*C columns")
+        ss_batch = ss.shape[0]
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty((B * groups,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    _lib.call("i2r_groupnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), ss_batch, _p(y), _p(mean), _p(rstd), B, C,
+              HW, groups, float(eps), int(bool(act)), float(drop_p), int(seed), int(offset), _stream())
+    return y, mean, rstd
+
+
+def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0):
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    part = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+    dss = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device) if ss is not None else None
+    _lib.call("i2r_groupnorm_bwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0], _p(mean),
+              _p(rstd), _p(dy), _p(dx), _p(part[0]), _p(part[1]), _p(dss), B, C, HW, groups, int(bool(act)),
+              float(drop_p), int(seed), int(offset), _stream())
+    dgb = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
+    # part viewed as (B, 2, C) would interleave; reduce each half separately
+    _lib.call("i2r_reduce_rows_f32", _p(part[0]), _p(dgb[:C]), B, C, _stream())
+    _lib.call("i2r_reduce_rows_f32", _p(part[1]), _vp(dgb.data_ptr() + 4 * C), B, C, _stream())
+    return dx, dgb[:C], dgb[C:], dss
+
+
+def attention_fwd(qkv, heads, save_lse=False):
+    _chk(qkv, "qkv")
+    B, C3 = qkv.shape[0], qkv.shape[1]
+    C = C3 // 3
+    if C != heads * 64:
+        raise ValueError(f"attention: channels {C} != heads*64 ({heads}*64); head dim is fixed at 64")
+    T = qkv.numel() // (B * C3)
+    out = torch.empty((B, C) + tuple(qkv.shape[2:]), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device) if save_lse else None
+    _lib.call("i2r_attention_fwd_f32", _p(qkv), _p(out), _p(lse), B, heads, T, _stream())
+    return out, lse
+
+
+def attention_bwd(qkv, out, lse, dout, heads):
+    _chk(dout, "dout")
+    B, C3 = qkv.shape[0], qkv.shape[1]
+    T = qkv.numel() // (B * C3)
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device)
+    _lib.call("i2r_attention_bwd_f32", _p(qkv), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws), B, heads, T, _stream())
+    return dqkv
+
+
+def pos_embedding(x, num_channels, max_positions=10000):
+    _chk(x, "noise_labels")
+    out = torch.empty((x.numel(), num_channels), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_pos_embedding_f32", _p(x), _p(out), x.numel(), num_channels, max_positions, _stream())
+    return out
+
+
+def linear_fwd(x, w, bias=None, act=False, save_pre=False):
+    _chk(x, "x"); _chk(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("linear: shape mismatch")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if (save_pre and act) else None
+    _lib.call("i2r_linear_fwd_f32", _p(x), _p(w), _p(bias), _p(y), _p(pre), M, K, N, int(bool(act)), _stream())
+    return y, pre
+
+
+def linear_bwd(x, w, dy, need_dx=True, need_dw=True):
+    M, K = x.shape
+    N = w.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w) if need_dw else None
+    _lib.call("i2r_linear_bwd_f32", _p(x), _p(w), _p(dy), _p(dx), _p(dw), M, K, N, _stream())
+    return dx, dw
+
+
+def silu_bwd(pre, dy):
+    dx = torch.empty_like(dy)
+    _lib.call("i2r_silu_bwd_f32", _p(pre), _p(dy), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def reduce_rows(x2d):
+    _chk(x2d, "x")
+    out = torch.empty((x2d.shape[1],), dtype=torch.float32, device=x2d.device)
+    _lib.call("i2r_reduce_rows_f32", _p(x2d), _p(out), x2d.shape[0], x2d.shape[1], _stream())
+    return out
+
+
+def add(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    y = torch.empty_like(a)
+    _lib.call("i2r_add_f32", _p(a), _p(b), _p(y), a.numel(), _stream())
+    return y
+
+
+def _sigma_vec(sigma, device):
+    s = sigma.to(device=device, dtype=torch.float32).reshape(-1)
+    return _c(s)
+
+
+def edm_scale_input(x, sigma, sigma_data):
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = _c(x)
+    _chk(x, "x", x.dtype)
+    B = x.shape[0]
+    chw = x.numel() // B
+    xin = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    c_noise = torch.empty((sigma.numel(),), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_edm_scale_input", _p(x), int(x.dtype == torch.float64), _p(sigma), sigma.numel(), _p(xin),
+              _p(c_noise), B, chw, float(sigma_data), _stream())
+    return xin, c_noise
+
+
+def edm_combine(x, F, sigma, sigma_data):
+    _chk(F, "F")
+    B = x.shape[0]
+    chw = x.numel() // B
+    D = torch.empty_like(F)
+    _lib.call("i2r_edm_combine", _p(x), int(x.dtype == torch.float64), _p(F), _p(sigma), sigma.numel(), _p(D), B, chw,
+              float(sigma_data), _stream())
+    return D
+
+
+def edm_combine_bwd(dD, sigma, sigma_data):
+    _chk(dD, "dD")
+    B = dD.shape[0]
+    dF = torch.empty_like(dD)
+    _lib.call("i2r_edm_combine_bwd", _p(dD), _p(sigma), sigma.numel(), _p(dF), B, dD.numel() // B, float(sigma_data),
+              _stream())
+    return dF
+
+
+def edm_noise(x, mask, P_mean, P_std, sigma_data, rnd=None, noise=None, seed=0, offset=0):
+    _chk(x, "x"); _chk(mask, "mask")
+    B = x.shape[0]
+    chw = x.numel() // B
+    xn = torch.empty_like(x)
+    sigma = torch.empty((B,), dtype=torch.float32, device=x.device)
+    weight = torch.empty_like(sigma)
+    if rnd is not None:
+        rnd = _c(rnd.to(device=x.device, dtype=torch.float32).reshape(-1))
+        assert rnd.numel() == B
+    if noise is not None:
+        noise = _chk(_c(noise.to(device=x.device, dtype=torch.float32)), "noise")
+        assert noise.numel() == x.numel()
+    _lib.call("i2r_edm_noise", _p(x), _p(mask), _p(rnd), _p(noise), _p(xn), _p(sigma), _p(weight), B, chw,
+              float(P_mean), float(P_std), float(sigma_data), int(seed), int(offset), _stream())
+    return xn, sigma, weight
+
+
+def nan_mask(x):
+    _chk(x, "x")
+    xc = torch.empty_like(x)
+    mask = torch.empty_like(x)
+    _lib.call("i2r_nan_mask_f32", _p(x), _p(xc), _p(mask), x.numel(), _stream())
+    return xc, mask
+
+
+def masked_edm_loss(D, x, mask, weight, want_grad=True):
+    _chk(D, "D"); _chk(x, "x"); _chk(mask, "mask"); _chk(weight, "weight")
+    B = D.shape[0]
+    loss = torch.empty((), dtype=torch.float32, device=D.device)
+    dD = torch.empty_like(D) if want_grad else None
+    partials = torch.empty((1024,), dtype=torch.float32, device=D.device)
+    _lib.call("i2r_masked_edm_loss", _p(D), _p(x), _p(mask), _p(weight), _p(loss), _p(dD), _p(partials), 1024, B,
+              D.numel() // B, _stream())
+    return loss, dD
+
+
+def heun_init(latents, t0):
+    _chk(latents, "latents")
+    x = torch.empty(latents.shape, dtype=torch.float64, device=latents.device)
+    _lib.call("i2r_heun_init_f64", _p(latents), _p(x), latents.numel(), float(t0), _stream())
+    return x
+
+
+def heun_euler(x_hat, D, d_cur, x_next, t_hat, t_next):
+    _lib.call("i2r_heun_euler_f64", _p(x_hat), _p(D), _p(d_cur), _p(x_next), x_hat.numel(), float(t_hat),
+              float(t_next), _stream())
+
+
+def heun_correct(x_hat, x_next, Dp, d_cur, x_out, t_hat, t_next):
+    _lib.call("i2r_heun_correct_f64", _p(x_hat), _p(x_next), _p(Dp), _p(d_cur), _p(x_out), x_hat.numel(),
+              float(t_hat), float(t_next), _stream())
+
+
+# ======================================================================================================= autograd
+class Conv2dFn(torch.autograd.Function):
+    """conv2d + bias + residual (networks.py:87-89 and the x.add_ of :178/:185)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return conv2d_fwd(x, w, bias, None if residual is None else _c(residual))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(dy, w)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(x, dy, w.shape[-1], want_bias=ctx.has_bias)
+        dres = dy if ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres
+
+
+class Down2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return down2(_c(x), 0.25)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return up2(_c(dy), 0.25)
+
+
+class Up2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return up2(_c(x), 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return down2(_c(dy), 1.0)
+
+
+class ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, c):
+        ctx.c1 = a.shape[1]
+        return concat_channels(_c(a), _c(c))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return split_channels(_c(dy), ctx.c1)
+
+
+class GroupNormFn(torch.autograd.Function):
+    """gn -> (1+scale)*.+shift -> SiLU -> dropout, one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, groups, eps, act, drop_p, seed, offset):
+        x = _c(x)
+        need_bwd = any(ctx.needs_input_grad[:4])
+        if ss is not None:
+            ss = _c(ss)
+        y, mean, rstd = groupnorm_fwd(x, gamma, beta, groups, eps, ss, act, need_bwd, drop_p, seed, offset)
+        if need_bwd:
+            ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
+            ctx.cfg = (groups, act, drop_p, seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, mean, rstd = ctx.saved_tensors
+        groups, act, drop_p, seed, offset = ctx.cfg
+        if ss is not None and ss.shape[0] != x.shape[0]:
+            raise _lib.I2RError("groupnorm backward needs per-sample scale/shift (sigma given per sample)")
+        dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset)
+        return dx, dg, db, dss, None, None, None, None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = _c(qkv)
+        need_bwd = ctx.needs_input_grad[0]
+        out, lse = attention_fwd(qkv, heads, save_lse=need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(qkv, out, lse)
+            ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        return attention_bwd(qkv, out, lse, _c(dout), ctx.heads), None
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        x = _c(x)
+        need_bwd = any(ctx.needs_input_grad[:3])
+        y, pre = linear_fwd(x, w, bias, act, save_pre=need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(x, w, pre)
+            ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        dy = _c(dy)
+        if pre is not None:
+            dy = silu_bwd(pre, dy)
+        dx, dw = linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = reduce_rows(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+class EdmCombineFn(torch.autograd.Function):
+    """D = c_skip x + c_out F (networks.py:667).  Only dF is propagated: the reference computes dL/dx too but
+    discards it, so the input image is treated as a constant."""
+
+    @staticmethod
+    def forward(ctx, x, F, sigma, sigma_data):
+        ctx.save_for_backward(sigma)
+        ctx.sd = sigma_data
+        return edm_combine(x, _c(F), sigma, sigma_data)
+
+    @staticmethod
+    def backward(ctx, dD):
+        (sigma,) = ctx.saved_tensors
+        return None, edm_combine_bwd(_c(dD), sigma, ctx.sd), None, None
+
+
+class MaskedLossFn(torch.autograd.Function):
+    """mean(weight * (D*mask - x*mask)^2) (our.py:64-66); forward also produces dL/dD."""
+
+    @staticmethod
+    def forward(ctx, D, x, mask, weight):
+        loss, dD = masked_edm_loss(_c(D), x, mask, weight, want_grad=ctx.needs_input_grad[0])
+        if dD is not None:
+            ctx.save_for_backward(dD)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dD,) = ctx.saved_tensors
+        return dD * g, None, None, None
+
+
+class TsToImgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ts, delay, embedding, cols, side, pad_value):
+        ctx.cfg = (ts.shape[1], delay, embedding, cols)
+        return ts_to_img(_c(ts), delay, embedding, cols, side, pad_value)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        L, delay, embedding, cols = ctx.cfg
+        return ts_to_img_bwd(_c(dimg), L, delay, embedding, cols), None, None, None, None, None

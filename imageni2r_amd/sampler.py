@@ -1,0 +1,118 @@
+"""DiffusionProcess: the 18-step Heun (EDM) sampler of models/sampler.py:4-71 with the whole loop -- 35 denoiser
+evaluations plus the fp64 state updates -- captured once into a HIP graph and replayed.
+
+Same constructor and ``sampling`` / ``sample`` signatures as the reference.  Differences that do not change results:
+the per-step tensor->bool host syncs (:50) are gone (the schedule lives on the host), and the dead
+``randn_like * 0`` draw (:52, S_churn = 0) is skipped -- it only advances the device RNG stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def karras_schedule(num_steps, sigma_min, sigma_max, rho):
+    """fp64 t_steps with t_N = 0 appended (:39-42), evaluated on the host with torch's own fp64 ops."""
+    step = torch.arange(num_steps, dtype=torch.float64)
+    t = (sigma_max ** (1 / rho) + step / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+class DiffusionProcess:
+    def __init__(self, args, diffusion_fn, shape, use_graph=True):
+        self.args = args
+        self.device = args.device
+        self.shape = tuple(shape)
+        # DDPM leftovers of the reference ctor (:16-20); unused by `sample`, kept as host attributes
+        self.betas = torch.linspace(start=args.beta1, end=args.betaT, steps=args.diffusion_steps)
+        self.alphas = 1 - self.betas
+        self.alpha_bars = torch.cumprod(self.alphas, dim=0)
+        self.alpha_prev_bars = torch.cat([torch.ones(1), self.alpha_bars[:-1]])
+        self.deterministic = args.deterministic
+        self.net = diffusion_fn.to(device=self.device)
+        self.sigma_data = 0.5
+        self.sigma_min = 0.002
+        self.sigma_max = 80
+        self.rho = 7
+        self.S_churn = 0
+        self.S_min = 0
+        self.S_max = float('inf')
+        self.S_noise = 1
+        self.num_steps = args.diffusion_steps
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    # ------------------------------------------------------------------------------------------------------
+    def _t_steps(self):
+        sigma_min = max(self.sigma_min, self.net.sigma_min)
+        sigma_max = min(self.sigma_max, self.net.sigma_max)
+        return karras_schedule(self.num_steps, sigma_min, sigma_max, self.rho)
+
+    def _loop(self, latents, t_host, sig_dev):
+        """The Heun loop (:45-63) on device buffers; t_host: python floats, sig_dev: fp32 device copy of t_steps."""
+        n = self.num_steps
+        x_cur = ops.heun_init(latents, t_host[0])
+        x_next = torch.empty_like(x_cur)
+        d_cur = torch.empty_like(x_cur)
+        x_out = torch.empty_like(x_cur)
+        for i in range(n):
+            t_cur, t_next = t_host[i], t_host[i + 1]
+            D = self.net(x_cur, sig_dev[i:i + 1])
+            ops.heun_euler(x_cur, D, d_cur, x_next, t_cur, t_next)
+            if i < n - 1:
+                Dp = self.net(x_next, sig_dev[i + 1:i + 2])
+                ops.heun_correct(x_cur, x_next, Dp, d_cur, x_out, t_cur, t_next)
+                x_cur, x_out = x_out, x_cur
+            else:
+                x_cur, x_next = x_next, x_cur
+        return x_cur
+
+    def _graph_key(self, latents):
+        return (tuple(latents.shape), latents.device.index,
+                hash(tuple(p.data_ptr() for p in self.net.parameters())))
+
+    @torch.no_grad()
+    def sample(self, latents, class_labels=None):
+        if self.S_churn != 0:
+            raise NotImplementedError("S_churn != 0 is never used by ImagenI2R (sampler.py:26)")
+        latents = latents.to(device=self.device, dtype=torch.float32).contiguous()
+        if not latents.is_cuda:
+            raise ops._lib.I2RError("DiffusionProcess: device must be a HIP ('cuda') device; no CPU fallback")
+        t_steps = self._t_steps()
+        t_host = [float(t) for t in t_steps]
+        was_training = self.net.training
+        self.net.eval()
+        try:
+            if not self.use_graph:
+                sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
+                return self._loop(latents, t_host, sig_dev)
+            key = self._graph_key(latents)
+            entry = self._graphs.get(key)
+            if entry is None:
+                sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
+                static_in = latents.clone()
+                # one eager pass on a side stream warms allocator + library state before capture
+                side = torch.cuda.Stream(device=latents.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._loop(static_in, t_host, sig_dev)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._loop(static_in, t_host, sig_dev)
+                entry = (graph, static_in, static_out, sig_dev)
+                self._graphs[key] = entry
+            graph, static_in, static_out, _ = entry
+            static_in.copy_(latents)
+            graph.replay()
+            return static_out.clone()
+        finally:
+            self.net.train(was_training)
+
+    @torch.no_grad()
+    def sampling(self, sampling_number=16, impute=False, xT=None):
+        if xT is None:
+            xT = torch.randn([sampling_number, *self.shape]).to(device=self.device)  # CPU draw like :70
+        return self.sample(xT)

@@ -1,0 +1,128 @@
+/* libi2r_hip.so -- C ABI of the MI355X (gfx950) masked-diffusion hot path of ImagenI2R.
+ *
+ * The reference (azencot-group/ImagenI2R) has no FFI: its boundary for this path is the Python object API
+ * (TS2img_Karras / EDMPrecond / DiffusionProcess / DelayEmbedder).  The host-side mirror of that API lives in
+ * imageni2r_amd/*.py; underneath it every arithmetic step of the path is one of the entry points below.  Each entry
+ * point cites the reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous memory (NCHW fp32 unless stated); the library never allocates,
+ *     frees or synchronises: outputs and workspaces are caller-owned (torch-allocated in the Python mirror);
+ *   - `stream` is a hipStream_t; all work is enqueued on it asynchronously and is safe under hipGraph stream capture;
+ *   - return value 0 = ok, negative = error (I2R_ERR_*), message via i2r_last_error() (thread-local);
+ *     shape/aliasing preconditions are checked on the host before anything is launched.
+ */
+#ifndef I2R_HIP_H
+#define I2R_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* i2r_stream_t; /* hipStream_t */
+
+int i2r_version(void);
+const char* i2r_last_error(void);
+
+/* ---- delay embedding: models/img_transformations.py ------------------------------------------------------------ */
+/* DelayEmbedder.ts_to_img + pad_to_square (:79-108, :59-70), fused with the observed-mask derivation
+ * run_irregular.py:216 (mask may be NULL).  ts (B,L,C) -> img, mask (B,C,S,S).  cols = image columns before padding. */
+int i2r_ts_to_img_f32(const float* ts, float* img, float* mask, int B, int L, int C, int delay, int E, int cols,
+                      int S, float pad_value, i2r_stream_t stream);
+/* adjoint of the above (autograd's CopySlices chain through :91/:98): dts (B,L,C) = gather-sum of dimg */
+int i2r_ts_to_img_bwd_f32(const float* dimg, float* dts, int B, int L, int C, int delay, int E, int cols, int S,
+                          i2r_stream_t stream);
+/* DelayEmbedder.img_to_ts (:140-170): mean over the cells of each time step, summed in ascending image row in the
+ * input dtype, true division by the count, stored fp32.  f64 variant = what the sampler's fp64 output goes through. */
+int i2r_img_to_ts_f32(const float* img, float* ts, int B, int L, int C, int delay, int E, int cols, int S,
+                      i2r_stream_t stream);
+int i2r_img_to_ts_f64(const double* img, float* ts, int B, int L, int C, int delay, int E, int cols, int S,
+                      i2r_stream_t stream);
+
+/* ---- convolutions: models/networks.py:68-90 (Conv2d.forward, non-fused resample path) ----------------------------- */
+/* out = conv2d(x, w, padding = ksize/2) + bias + residual   (bias, residual may be NULL; w is OIHW; ksize 1 or 3).
+ * `residual` fuses the x.add_(skip) / proj(...).add_(x) of UNetBlock.forward (:178, :185). */
+int i2r_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
+                       int Cin, int H, int W, int Cout, int ksize, i2r_stream_t stream);
+/* autograd of the above w.r.t. x: dx = conv2d(dy, flip(w)^T).  wt_ws: workspace of Cout*Cin*ksize^2 floats. */
+int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* wt_ws, float* dx, int B, int Cin, int H, int W,
+                         int Cout, int ksize, i2r_stream_t stream);
+int i2r_conv2d_weight_flip_f32(const float* w, float* wt, int Cout, int Cin, int ksize, i2r_stream_t stream);
+/* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) is overwritten; dbias (Cout) may be NULL. */
+int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
+                         int Cout, int ksize, i2r_stream_t stream);
+/* resample_filter [1,1] (:64-65, :82-85): y = scale * 2x2 box sum (down; scale 0.25 forward) and
+ * y = scale * nearest x2 (up; scale 1 forward); each is the other's adjoint with the scales swapped. */
+int i2r_down2_f32(const float* x, float* y, long planes, int H, int W, float scale, i2r_stream_t stream);
+int i2r_up2_f32(const float* x, float* y, long planes, int H, int W, float scale, i2r_stream_t stream);
+/* torch.cat([x, skip], dim=1) of DhariwalUNet.forward (:458) and its adjoint. n1, n2 = C1*H*W, C2*H*W. */
+int i2r_concat_channels_f32(const float* a, const float* c, float* out, int B, long n1, long n2, i2r_stream_t stream);
+int i2r_split_channels_f32(const float* in, float* a, float* c, int B, long n1, long n2, int accumulate_c,
+                           i2r_stream_t stream);
+
+/* ---- GroupNorm family: models/networks.py:104-106 fused with its consumers (:168, :173, :177, :182, :460) ---------- */
+/* y = dropout_p( act( gn(x; gamma, beta, G, eps) * (1 + scale) + shift ) );  ss = [scale | shift] (ss_batch, 2C) or
+ * NULL; act: 0 identity, 1 SiLU; mean/rstd (B*G) optional outputs for backward; dropout mask = Philox(seed, offset). */
+int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
+                          float* y, float* mean, float* rstd, int B, int C, int HW, int G, float eps, int act,
+                          float drop_p, uint64_t seed, uint64_t offset, i2r_stream_t stream);
+/* backward: dx (B,C,HW); dgamma_part, dbeta_part (B,C) per-sample partials (reduce with i2r_reduce_rows_f32);
+ * dss (B,2C) = [dscale | dshift] iff ss given. */
+int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
+                          const float* mean, const float* rstd, const float* dy, float* dx, float* dgamma_part,
+                          float* dbeta_part, float* dss, int B, int C, int HW, int G, int act, float drop_p,
+                          uint64_t seed, uint64_t offset, i2r_stream_t stream);
+int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream);
+
+/* ---- attention: models/networks.py:113-126 (AttentionOp) + :182-184 ---------------------------------------------- */
+/* qkv (B, 3*heads*64, T) interleaved (head, d, {q,k,v}); out (B, heads*64, T); lse (B*heads*T) optional (backward). */
+int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T, i2r_stream_t stream);
+/* AttentionOp.backward (:121-126) + einsum backward: dqkv (B,3C,T); delta_ws: workspace of B*heads*T floats. */
+int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                          float* delta_ws, int B, int heads, int T, i2r_stream_t stream);
+
+/* ---- embedding path: models/networks.py:200-206 (PositionalEmbedding), :39-43 (Linear) ---------------------------- */
+int i2r_pos_embedding_f32(const float* x, float* out, int B, int num_channels, int max_positions,
+                          i2r_stream_t stream);
+/* y = act(x W^T + b); x (M,K), w (N,K); pre (M,N) optional pre-activation copy; act_silu fuses silu (:440,:447). */
+int i2r_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int K, int N,
+                       int act_silu, i2r_stream_t stream);
+int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, int M, int K, int N,
+                       i2r_stream_t stream);
+int i2r_silu_bwd_f32(const float* pre, const float* dy, float* dx, long n, i2r_stream_t stream);
+int i2r_add_f32(const float* a, const float* b, float* y, long n, i2r_stream_t stream);
+
+/* ---- EDM preconditioning: models/networks.py:654-668 --------------------------------------------------------------- */
+/* xin = c_in(sigma) * float(x), c_noise = ln(sigma)/4 (:662-665); x fp32 or fp64; sigma: nsig = 1 (broadcast) or B. */
+int i2r_edm_scale_input(const void* x, int x_is_f64, const float* sigma, int nsig, float* xin, float* c_noise, int B,
+                        long chw, float sigma_data, i2r_stream_t stream);
+/* D = c_skip * float(x) + c_out * F (:660-661, :667) */
+int i2r_edm_combine(const void* x, int x_is_f64, const float* F, const float* sigma, int nsig, float* D, int B,
+                    long chw, float sigma_data, i2r_stream_t stream);
+int i2r_edm_combine_bwd(const float* dD, const float* sigma, int nsig, float* dF, int B, long chw, float sigma_data,
+                        i2r_stream_t stream);
+
+/* ---- masked EDM loss: models/our.py:53-78 -------------------------------------------------------------------------- */
+/* forward_irregular (:71-77): sigma = exp(rnd*P_std+P_mean), weight, xn = x + (noise*sigma)*mask.  rnd_in (B) and
+ * noise_in (B*chw) inject the two random draws (parity tests); when NULL they are drawn in-kernel (Philox). */
+int i2r_edm_noise(const float* x, const float* mask, const float* rnd_in, const float* noise_in, float* xn,
+                  float* sigma, float* weight, int B, long chw, float P_mean, float P_std, float sigma_data,
+                  uint64_t seed, uint64_t offset, i2r_stream_t stream);
+/* mask = 1 - isnan(x), x_clean = nan_to_num(x, 0): the mask=None branch of loss_fn_irregular (:60-62) */
+int i2r_nan_mask_f32(const float* x, float* x_clean, float* mask, long n, i2r_stream_t stream);
+/* loss_fn_irregular (:63-66): loss = mean(weight * (D*mask - x*mask)^2) over all B*chw elements; dD (optional) is
+ * d loss / d D.  partials: workspace of n_partials (>= 1, ideally 1024) floats. */
+int i2r_masked_edm_loss(const float* D, const float* x, const float* mask, const float* weight, float* loss,
+                        float* dD, float* partials, int n_partials, int B, long chw, i2r_stream_t stream);
+
+/* ---- Heun sampler updates: models/sampler.py:45, :56-57, :62-63 (fp64 state, fp32 denoiser output) ------------------ */
+int i2r_heun_init_f64(const float* latents, double* x, long n, double t0, i2r_stream_t stream);
+int i2r_heun_euler_f64(const double* x_hat, const float* D, double* d_cur, double* x_next, long n, double t_hat,
+                       double t_next, i2r_stream_t stream);
+int i2r_heun_correct_f64(const double* x_hat, const double* x_next, const float* Dp, const double* d_cur,
+                         double* x_out, long n, double t_hat, double t_next, i2r_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2R_HIP_H */
