@@ -1,0 +1,407 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI (ctypes), against the golden vectors
+captured from the reference and against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): delay embedding and masks bit-exact; fp32 outputs and gradients <= 1e-4 relative
+(max |a-b| / max |b|)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import as_f32, as_f64, golden_meta, load_golden, probe_vec, rel_err, tiny_args
+from oracle import i2r_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from imageni2r_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------------ delay embedding
+def test_delay_embedding_bit_exact(ops):
+    from imageni2r_amd import DelayEmbedder
+    g = load_golden("g1_delay.npz")
+    for m in golden_meta(g):
+        t = m["tag"]
+        emb = DelayEmbedder(DEV, m["L"], m["d"], m["E"], m["B"], m["C"])
+        ts = cu(as_f32(g[t + "_ts"]))
+        img = emb.ts_to_img(ts)
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), g[t + "_img"]), t
+        img2, mask = emb.ts_to_img_with_mask(ts)
+        assert np.array_equal(img2.cpu().numpy().view(np.uint32), g[t + "_img"]), t
+        assert np.array_equal(mask.cpu().numpy(), g[t + "_mask"]), t
+        assert tuple(emb.img_shape) == tuple(g[t + "_img_shape"])
+        for name, conv in (("f32", as_f32), ("f64", as_f64)):
+            y = emb.img_to_ts(cu(conv(g[t + f"_inv_in_{name}"])))
+            assert y.dtype == torch.float32
+            assert np.array_equal(y.cpu().numpy().view(np.uint32), g[t + f"_inv_out_{name}"]), (t, name)
+
+
+def test_delay_embedding_full_size_roundtrip_and_backward(ops):
+    """BASELINE shapes B1 / C / D: embed -> inverse reproduces the series up to the 1-ulp averaging of
+    overlapped cells, and the adjoint kernel equals the oracle's autograd."""
+    from imageni2r_amd import DelayEmbedder
+    for (B, L, C, d, E) in ((32, 96, 12, 6, 16), (32, 96, 321, 6, 16), (32, 768, 7, 24, 32)):
+        gen = torch.Generator().manual_seed(L + C)
+        ts = torch.rand(B, L, C, generator=gen)
+        emb = DelayEmbedder(DEV, L, d, E, B, C)
+        img = emb.ts_to_img(ts.to(DEV))
+        assert np.array_equal(img.cpu().numpy(), O.ts_to_img(ts.numpy(), d, E))
+        back = emb.img_to_ts(img)
+        assert np.array_equal(back.cpu().numpy(), O.img_to_ts(img.cpu().numpy(), L, d, E))
+        assert (back.cpu() - ts).abs().max() < 2e-7
+    cols, S = O.delay_geometry(96, 6, 16)
+    dimg = torch.randn(2, 3, S, S)
+    dts = ops.ts_to_img_bwd(dimg.to(DEV), 96, 6, 16, cols).cpu().numpy()
+    idx = O.delay_index_map(96, 6, 16)
+    ref = np.zeros((2, 96, 3), dtype=np.float64)
+    for r in range(16):
+        for c in range(cols):
+            if idx[r, c] >= 0:
+                ref[:, idx[r, c], :] += dimg[:, :, r, c].numpy()
+    assert rel_err(dts, ref) < 1e-6
+
+
+def test_delay_edge_cases(ops):
+    from imageni2r_amd import DelayEmbedder
+    # delay > embedding: some time steps have no image cell and must come back as 0 (img_transformations.py:153-155)
+    emb = DelayEmbedder(DEV, 24, 10, 8, 2, 1)
+    ts = torch.rand(2, 24, 1)
+    img = emb.ts_to_img(ts.to(DEV))
+    assert np.array_equal(img.cpu().numpy(), O.ts_to_img(ts.numpy(), 10, 8))
+    back = emb.img_to_ts(img).cpu().numpy()
+    assert np.array_equal(back, O.img_to_ts(img.cpu().numpy(), 24, 10, 8))
+    assert (back[:, 8:10, :] == 0).all()
+    # all-NaN series
+    ts = torch.full((1, 24, 2), float("nan"))
+    emb = DelayEmbedder(DEV, 24, 3, 8, 1, 2)
+    img, mask = emb.ts_to_img_with_mask(ts.to(DEV))
+    assert np.array_equal(mask.cpu().numpy(), O.observed_mask(O.ts_to_img(ts.numpy(), 3, 8)))
+
+
+# ------------------------------------------------------------------------------------------------ layers (golden G3)
+def test_pos_embedding(ops):
+    g = load_golden("g3_layers.npz")
+    out = ops.pos_embedding(cu(g["pe_in"]), 128).cpu().numpy()
+    assert rel_err(out, g["pe_out"]) < 1e-6
+
+
+@pytest.mark.parametrize("C,H", [(64, 8), (128, 4), (96, 2)])
+def test_groupnorm_golden(ops, C, H):
+    g = load_golden("g3_layers.npz")
+    t = f"gn_C{C}_H{H}"
+    x, w, b, dy = cu(g[t + "_x"]), cu(g[t + "_w"]), cu(g[t + "_b"]), cu(g[t + "_dy"])
+    G = min(32, C // 4)
+    y, mean, rstd = ops.groupnorm_fwd(x, w, b, G, 1e-5, save_stats=True)
+    assert rel_err(y.cpu().numpy(), g[t + "_y"]) < TOL
+    dx, dw, db, _ = ops.groupnorm_bwd(x, w, b, None, mean, rstd, dy, G, False)
+    assert rel_err(dx.cpu().numpy(), g[t + "_dx"]) < TOL
+    assert rel_err(dw.cpu().numpy(), g[t + "_dw"]) < TOL
+    assert rel_err(db.cpu().numpy(), g[t + "_db"]) < TOL
+
+
+def test_groupnorm_fused_modes_vs_oracle(ops):
+    torch.manual_seed(11)
+    B, C, H = 3, 128, 8
+    x = torch.randn(B, C, H, H) * 2 + 0.5
+    w, b = torch.randn(C), torch.randn(C)
+    ss = (torch.randn(B, 2 * C) * 0.5).requires_grad_(True)
+    dy = torch.randn(B, C, H, H)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    scale, shift = ss[:, :C, None, None], ss[:, C:, None, None]
+    ref = torch.nn.functional.silu(shift + O.group_norm(xr, wr, br) * (scale + 1))
+    ref.backward(dy)
+    y, mean, rstd = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5,
+                                      ss=cu(ss.detach().numpy()), act=True, save_stats=True)
+    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+    dx, dw, db, dss = ops.groupnorm_bwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), cu(ss.detach().numpy()), mean,
+                                        rstd, cu(dy.numpy()), 32, True)
+    assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
+    assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
+    assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+    assert rel_err(dss.cpu().numpy(), ss.grad.numpy()) < TOL
+    # broadcast (batch-1) modulation as used by the sampler + SiLU-only mode
+    y1, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5,
+                                 ss=cu(ss.detach().numpy()[:1]), act=True)
+    ref1 = torch.nn.functional.silu(ss[:1, C:, None, None] + O.group_norm(x, w, b) * (ss[:1, :C, None, None] + 1))
+    assert rel_err(y1.cpu().numpy(), ref1.detach().numpy()) < TOL
+    y2, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5, act=True)
+    assert rel_err(y2.cpu().numpy(), torch.nn.functional.silu(O.group_norm(x, w, b)).numpy()) < TOL
+
+
+def test_groupnorm_dropout_is_consistent(ops):
+    """Dropout masks are regenerated from (seed, offset): forward keep-rate ~ 1-p, surviving values are scaled by
+    1/(1-p), and backward uses the same mask."""
+    torch.manual_seed(5)
+    B, C, H, p = 4, 128, 16, 0.1
+    x = torch.randn(B, C, H, H)
+    w, b = torch.ones(C), torch.zeros(C)
+    xd, wd, bd = cu(x.numpy()), cu(w.numpy()), cu(b.numpy())
+    y0, mean, rstd = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, save_stats=True)
+    y1, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=123, offset=7)
+    y1b, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=123, offset=7)
+    y2, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=123, offset=8)
+    assert torch.equal(y1, y1b) and not torch.equal(y1, y2)
+    keep = (y1 != 0)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01
+    assert torch.allclose(y1[keep], y0[keep] / (1 - p), rtol=1e-6, atol=1e-7)
+    dy = torch.ones_like(xd)
+    dxa, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy * keep.float() / (1 - p), 32, False)
+    dxb, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy, 32, False, drop_p=p, seed=123, offset=7)
+    assert rel_err(dxb.cpu().numpy(), dxa.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["c3", "c1", "c3up", "c3down", "k0up", "k0down", "c3_1x1sp"])
+def test_conv_golden(ops, name):
+    from imageni2r_amd import Conv2d
+    g = load_golden("g3_layers.npz")
+    t = "conv_" + name
+    has_w = (t + "_w") in g
+    x = cu(g[t + "_x"]).requires_grad_(True)
+    kernel = 0 if not has_w else g[t + "_w"].shape[-1]
+    conv = Conv2d(x.shape[1], g[t + "_y"].shape[1], kernel, up="up" in name, down="down" in name)
+    if has_w:
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(g[t + "_w"]))
+            conv.bias.copy_(torch.from_numpy(g[t + "_b"]))
+    conv = conv.to(DEV)
+    y = conv(x)
+    y.backward(cu(g[t + "_dy"]))
+    assert rel_err(y.detach().cpu().numpy(), g[t + "_y"]) < TOL
+    assert rel_err(x.grad.cpu().numpy(), g[t + "_dx"]) < TOL
+    if has_w:
+        assert rel_err(conv.weight.grad.cpu().numpy(), g[t + "_dw"]) < TOL
+        assert rel_err(conv.bias.grad.cpu().numpy(), g[t + "_db"]) < TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 128, 128, 16, 3), (2, 384, 256, 8, 3), (3, 1024, 512, 2, 3),
+                                            (2, 12, 128, 16, 3), (2, 128, 12, 16, 3), (2, 256, 768, 8, 1),
+                                            (5, 321, 128, 16, 3), (2, 128, 321, 16, 3), (3, 256, 256, 1, 3),
+                                            (2, 768, 256, 4, 1), (33, 64, 96, 4, 3), (1, 7, 128, 32, 3)])
+def test_conv_shapes_vs_oracle(ops, B, Cin, Cout, H, k):
+    """Every tile variant / edge (ragged Cout, ragged positions, tiny K, 1x1 spatial) of fwd, dgrad and wgrad."""
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, H, generator=gen)
+    dy = torch.randn(B, Cout, H, H, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=k // 2) + res
+    ref.backward(dy)
+    y = ops.conv2d_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), cu(res.numpy()))
+    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+    dx = ops.conv2d_dgrad(cu(dy.numpy()), cu(w.numpy()))
+    assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
+    dw, db = ops.conv2d_wgrad(cu(x.numpy()), cu(dy.numpy()), k)
+    assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
+    assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("heads,C,H", [(1, 64, 4), (2, 128, 8), (2, 128, 1)])
+def test_attention_golden(ops, heads, C, H):
+    g = load_golden("g3_layers.npz")
+    t = f"attn_h{heads}_C{C}_H{H}"
+    qkv = cu(g[t + "_qkv"])
+    a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
+    assert rel_err(a.cpu().numpy(), g[t + "_a"]) < TOL
+    dqkv = ops.attention_bwd(qkv, a, lse, cu(g[t + "_da"]), heads)
+    assert rel_err(dqkv.cpu().numpy(), g[t + "_dqkv"]) < TOL
+
+
+@pytest.mark.parametrize("B,heads,H", [(2, 2, 16), (1, 4, 32), (3, 8, 2), (2, 4, 4), (1, 2, 8)])
+def test_attention_shapes_vs_oracle(ops, B, heads, H):
+    """T = 256 and 1024 (flash path, several key tiles), T = 4, 16 (LDS path), T = 64."""
+    gen = torch.Generator().manual_seed(B + heads + H)
+    C = heads * 64
+    qkv = (torch.randn(B, 3 * C, H, H, generator=gen) * 1.5).requires_grad_(True)
+    da = torch.randn(B, C, H, H, generator=gen)
+    ref = O.attention(qkv, heads)
+    ref.backward(da)
+    q = cu(qkv.detach().numpy())
+    a, lse = ops.attention_fwd(q, heads, save_lse=True)
+    assert rel_err(a.cpu().numpy(), ref.detach().numpy()) < TOL
+    dqkv = ops.attention_bwd(q, a, lse, cu(da.numpy()), heads)
+    assert rel_err(dqkv.cpu().numpy(), qkv.grad.numpy()) < TOL
+
+
+def test_attention_large_scores_online_softmax(ops):
+    """Force the running-max rescale branch: one key tile far larger than the earlier ones."""
+    gen = torch.Generator().manual_seed(3)
+    B, heads, H = 1, 1, 16
+    qkv = torch.randn(B, 192, H, H, generator=gen)
+    qkv.view(B, 64, 3, H * H)[:, :, 1, 200:] *= 6.0  # keys in late tiles dominate
+    ref = O.attention(qkv, heads)
+    a, _ = ops.attention_fwd(cu(qkv.numpy()), heads)
+    assert rel_err(a.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_linear_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(9)
+    for M, K, N, act in ((1, 128, 512, True), (32, 512, 512, True), (7, 512, 1024, False), (4, 32, 33, False)):
+        x = torch.randn(M, K, generator=gen, requires_grad=True)
+        w = (torch.randn(N, K, generator=gen) / np.sqrt(K)).requires_grad_(True)
+        b = torch.randn(N, generator=gen, requires_grad=True)
+        dy = torch.randn(M, N, generator=gen)
+        ref = O.linear(x, w, b)
+        ref = torch.nn.functional.silu(ref) if act else ref
+        ref.backward(dy)
+        xd, wd, bd = cu(x.detach().numpy()).requires_grad_(True), cu(w.detach().numpy()).requires_grad_(True), \
+            cu(b.detach().numpy()).requires_grad_(True)
+        y = ops.LinearFn.apply(xd, wd, bd, act)
+        y.backward(cu(dy.numpy()))
+        assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+        assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < TOL
+        assert rel_err(wd.grad.cpu().numpy(), w.grad.numpy()) < TOL
+        assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("name,cin,cout,kw", [("plain", 16, 16, {}), ("down", 16, 16, dict(down=True)),
+                                              ("up", 16, 16, dict(up=True)), ("chg", 24, 16, {}),
+                                              ("attn", 32, 64, dict(attention=True))])
+def test_unet_block_golden(ops, name, cin, cout, kw):
+    from imageni2r_amd import UNetBlock
+    g = load_golden("g3_layers.npz")
+    t = "blk_" + name
+    blk = UNetBlock(in_channels=cin, out_channels=cout, emb_channels=32, dropout=0.10, **kw).eval()
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            p.copy_(torch.from_numpy(g[t + "_p_" + k]))
+    blk = blk.to(DEV)
+    x = cu(g[t + "_x"]).requires_grad_(True)
+    y = blk(x, cu(g[t + "_emb"]))
+    y.backward(cu(g[t + "_dy"]))
+    assert rel_err(y.detach().cpu().numpy(), g[t + "_y"]) < TOL
+    assert rel_err(x.grad.cpu().numpy(), g[t + "_dx"]) < TOL
+    for k, p in blk.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), g[t + "_g_" + k]) < TOL, k
+
+
+# ------------------------------------------------------------------------------------------------ net / loss / sampler
+@pytest.fixture(scope="module")
+def tiny_gpu():
+    from imageni2r_amd import TS2img_Karras
+    torch.manual_seed(0)
+    m = TS2img_Karras(tiny_args(device=DEV), DEV)
+    O.perturb_zero_init(m.net.state_dict(), seed=1234)
+    return m.to(DEV).eval()
+
+
+def test_denoiser_golden(tiny_gpu):
+    g = load_golden("g4_net.npz")
+    with torch.no_grad():
+        D = tiny_gpu.net(cu(g["x"]), cu(g["sigma"]))
+        assert rel_err(D.cpu().numpy(), g["D_per_sample"]) < TOL
+        D2 = tiny_gpu.net(cu(g["x"]).double(), torch.tensor(1.7, dtype=torch.float64))
+        assert D2.dtype == torch.float32
+        assert rel_err(D2.cpu().numpy(), g["D_scalar_sigma"]) < TOL
+
+
+def test_loss_and_gradients_golden(tiny_gpu):
+    g = load_golden("g4_net.npz")
+    m = tiny_gpu
+    m.zero_grad()
+    m.inject_randomness(cu(g["loss_rnd"]), cu(g["loss_noise"]))
+    try:
+        loss, to_log = m.loss_fn_irregular(cu(g["loss_x_tilde"]), cu(g["loss_mask"]))
+        assert isinstance(to_log["karras loss"], float)
+        assert abs(loss.item() - g["loss_value"][0]) <= TOL * abs(g["loss_value"][0])
+        loss.backward()
+        names = json.loads(bytes(g["grad_names"]).decode())
+        params = dict(m.net.named_parameters())
+        assert list(params.keys()) == names
+        summ = g["grad_summary"]
+        for i, k in enumerate(names):
+            gr = params[k].grad.double().cpu().numpy().ravel()
+            got = np.array([gr.sum(), (gr * gr).sum(), (gr * probe_vec(gr.size, 9000 + i)).sum()])
+            scale = max(np.sqrt(summ[i][1]) * np.sqrt(gr.size), 1e-12)
+            assert abs(got[1] - summ[i][1]) <= 2 * TOL * max(summ[i][1], 1e-20), k
+            assert abs(got[0] - summ[i][0]) <= TOL * scale, k
+            assert abs(got[2] - summ[i][2]) <= TOL * scale, k
+            if ("grad_full_" + k) in g:
+                assert rel_err(params[k].grad.cpu().numpy(), g["grad_full_" + k]) < TOL, k
+        # mask=None branch (NaN-derived mask)
+        x_img = m.ts_to_img(cu(as_f32(g["loss_ts"])))
+        loss2, _ = m.loss_fn_irregular(x_img, None)
+        assert abs(loss2.item() - g["loss_value_nanmask"][0]) <= TOL * abs(g["loss_value_nanmask"][0])
+    finally:
+        m.inject_randomness(None, None)
+        m.zero_grad()
+
+
+def test_full_gradients_vs_oracle(tiny_gpu):
+    """Every parameter gradient, element by element, against the oracle's autograd on the same inputs."""
+    g = load_golden("g4_net.npz")
+    m = tiny_gpu
+    a = tiny_args()
+    spec = O.unet_spec(a.img_resolution, a.input_channels, a.unet_channels, a.ch_mult, a.attn_resolution)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.net.state_dict().items()
+          if not k.endswith("resample_filter")}
+    ref = O.masked_edm_loss(sd, spec, torch.from_numpy(g["loss_x_tilde"]), torch.from_numpy(g["loss_mask"]),
+                            torch.from_numpy(g["loss_rnd"]), torch.from_numpy(g["loss_noise"]))
+    ref.backward()
+    m.zero_grad()
+    m.inject_randomness(cu(g["loss_rnd"]), cu(g["loss_noise"]))
+    try:
+        loss, _ = m.loss_fn_irregular(cu(g["loss_x_tilde"]), cu(g["loss_mask"]))
+        loss.backward()
+    finally:
+        m.inject_randomness(None, None)
+    worst = 0.0
+    for k, p in m.net.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy())
+        worst = max(worst, e)
+        assert e < TOL, (k, e)
+    m.zero_grad()
+
+
+def test_sampler_golden(tiny_gpu):
+    from imageni2r_amd import DiffusionProcess
+    g = load_golden("g5_sampler.npz")
+    args = tiny_args(device=DEV)
+    for use_graph in (False, True):
+        proc = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8), use_graph=use_graph)
+        out = proc.sampling(sampling_number=2, xT=torch.from_numpy(g["xT"]))
+        assert out.dtype == torch.float64 and tuple(out.shape) == (2, 3, 8, 8)
+        assert rel_err(out.cpu().numpy(), g["out"]) < TOL, use_graph
+        if use_graph:  # replay gives the same answer again, and a new xT gives a different one
+            out2 = proc.sampling(sampling_number=2, xT=torch.from_numpy(g["xT"]))
+            assert torch.equal(out, out2)
+            out3 = proc.sampling(sampling_number=2)
+            assert not torch.equal(out, out3)
+    tiny_gpu.ts_img.img_shape = (2, 3, 8, 7)
+    ts = tiny_gpu.img_to_ts(out)
+    ref_ts = as_f32(g["ts_out"])
+    assert rel_err(ts.cpu().numpy(), ref_ts) < TOL
+
+
+def test_training_step_with_dropout_runs(tiny_gpu):
+    """train() mode: dropout live, in-kernel Philox noise; loss finite, every parameter gets a finite gradient."""
+    m = tiny_gpu
+    m.train()
+    try:
+        ts = torch.rand(4, 24, 3)
+        ts[0, [2, 3], :] = float("nan")
+        x_img, mask = m.ts_to_img_with_mask(ts.to(DEV))
+        x_tilde = m.ts_to_img(torch.rand(4, 24, 3).to(DEV))
+        loss, _ = m.loss_fn_irregular(x_tilde, mask)
+        loss.backward()
+        assert torch.isfinite(loss)
+        for k, p in m.net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        m.on_train_batch_end()
+    finally:
+        m.eval()
+        m.zero_grad()
