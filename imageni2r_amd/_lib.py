@@ -22,9 +22,12 @@ SIGNATURES = {
     "i2r_ts_to_img_bwd_f32": [P, P, I, I, I, I, I, I, I, P],
     "i2r_img_to_ts_f32": [P, P, I, I, I, I, I, I, I, P],
     "i2r_img_to_ts_f64": [P, P, I, I, I, I, I, I, I, P],
-    "i2r_conv2d_fwd_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
-    "i2r_conv2d_dgrad_f32": [P, P, P, P, I, I, I, I, I, I, P],
-    "i2r_conv2d_weight_flip_f32": [P, P, I, I, I, P],
+    "i2r_conv2d_packed_floats": [I, I, I, I],
+    "i2r_conv2d_pack_weight_f32": [P, P, I, I, I, I, P],
+    "i2r_conv2d_splitk_floats": [I, I, I, I, I, I],
+    "i2r_conv2d_fwd_packed_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "i2r_conv2d_fwd_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "i2r_conv2d_dgrad_f32": [P, P, P, L, P, I, I, I, I, I, I, P],
     "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
     "i2r_up2_f32": [P, P, L, I, I, F, P],
@@ -51,6 +54,8 @@ SIGNATURES = {
     "i2r_heun_correct_f64": [P, P, P, P, P, L, D, D, P],
 }
 
+RETURNS_LONG = {"i2r_conv2d_packed_floats", "i2r_conv2d_splitk_floats"}
+
 _lib = None
 
 
@@ -71,11 +76,16 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library is stale
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_long if name in RETURNS_LONG else c_int
     lib.i2r_last_error.argtypes = []
     lib.i2r_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib
+
+
+def query(name: str, *args) -> int:
+    """Call a size-query entry point (returns a count, never an error code)."""
+    return int(getattr(load(), name)(*args))
 
 
 def call(name: str, *args):

@@ -1,0 +1,183 @@
+// Weight gradient of the 3x3 / 1x1 convolutions (autograd of torch.nn.functional.conv2d, models/networks.py:87) on
+// the fp32 MFMA:   dW[co][j] = sum_n dY[co][n] * Im2col[j][n],  j = (ci, r, s) in OIHW order, n = (b, y, x).
+// The reduction runs over positions; it is split over blockIdx.z (fp32 atomics into a zeroed dW) when a single pass
+// would leave CUs idle.  Bias gradient: one wave per channel.
+#include "conv_common.h"
+#include "../../include/i2r_hip.h"
+
+#define BK 16
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct WgradParams {
+  const float* x;   // forward input (B, Cin, H, W)
+  const float* dy;  // output gradient (B, Cout, H, W)
+  float* dw;        // (Cout, Cin*KS*KS); zero-filled by the caller when nsplit > 1
+  int B, Cin, H, W, Cout, HW, K;
+  long Npos;
+  int chunks_per_split, nsplit;
+};
+
+template <int WM, int WN, int TM, int TN, int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+  __shared__ float smem[2 * BK * LDA + 2 * BK * LDB];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * BM;  // output channel tile
+  const int j0 = blockIdx.x * BN;  // (ci, tap) tile
+  const int kk = tid & 15, i0 = tid >> 4;
+
+  // per-thread constant decode of its EB im2col columns
+  int coff[EB], dr[EB], ds[EB];
+  bool jok[EB];
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    int j = j0 + i0 + 16 * e;
+    jok[e] = j < p.K;
+    int ci = (KS == 3) ? j / 9 : j;
+    int tap = (KS == 3) ? j - 9 * ci : 0;
+    int r = tap / 3, s = tap - 3 * r;
+    coff[e] = ci * p.HW;
+    dr[e] = (KS == 3) ? r - 1 : 0;
+    ds[e] = (KS == 3) ? s - 1 : 0;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float ra[EA], rb[EB];
+  auto load_chunk = [&](long nbase) {
+    long n = nbase + kk;
+    bool nv = n < p.Npos;
+    int b = 0, y = 0, x = 0, pos = 0;
+    if (nv) {
+      b = (int)(n / p.HW);
+      pos = (int)(n % p.HW);
+      y = pos / p.W;
+      x = pos % p.W;
+    }
+    const float* dyb = p.dy + (long)b * p.Cout * p.HW + pos;
+    const float* xb = p.x + (long)b * p.Cin * p.HW;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      int co = m0 + i0 + 16 * e;
+      ra[e] = (nv && co < p.Cout) ? dyb[(long)co * p.HW] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      int iy = y + dr[e], ix = x + ds[e];
+      float v = 0.0f;
+      if (nv && jok[e] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = xb[coff[e] + iy * p.W + ix];
+      rb[e] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* a = As + buf * BK * LDA;
+    float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) a[kk * LDA + i0 + 16 * e] = ra[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) b[kk * LDB + i0 + 16 * e] = rb[e];
+  };
+
+  const long total_chunks = (p.Npos + BK - 1) / BK;
+  long c_begin = (long)blockIdx.z * p.chunks_per_split;
+  long c_end = c_begin + p.chunks_per_split;
+  if (c_end > total_chunks) c_end = total_chunks;
+  if (c_begin < c_end) {
+    load_chunk(c_begin * BK);
+    store_chunk(0);
+    __syncthreads();
+    for (long c = c_begin; c < c_end; ++c) {
+      int cur = (int)((c - c_begin) & 1);
+      if (c + 1 < c_end) load_chunk((c + 1) * BK);
+      mma_chunk<WM, WN, TM, TN, BK>(As + cur * BK * LDA, Bs + cur * BK * LDB, LDA, LDB, acc, wm, wn, l31, h);
+      if (c + 1 < c_end) store_chunk(cur ^ 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    int j = j0 + (wn * TN + tn) * 32 + l31;
+    if (j >= p.K) continue;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout) {
+          float* dst = p.dw + (long)co * p.K + j;
+          if (p.nsplit > 1)
+            atomicAdd(dst, acc[tm][tn][r]);
+          else
+            *dst = acc[tm][tn][r];
+        }
+      }
+    }
+  }
+}
+
+// db[co] = sum_{b,pos} dy[b][co][pos]: one wave per channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
+                                                        int C, int HW) {
+  int lane = threadIdx.x & 63;
+  int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float acc = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = dy + ((long)b * C + c) * HW;
+    for (int i = lane; i < HW; i += 64) acc += p[i];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) db[c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <int WM, int WN, int TM, int TN>
+static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  long tiles = (long)i2r_cdiv(p.K, BN) * i2r_cdiv(p.Cout, BM);
+  long total_chunks = (p.Npos + BK - 1) / BK;
+  long want = (1024 + tiles - 1) / tiles;  // aim for ~4 blocks per CU
+  if (want > total_chunks / 4) want = total_chunks / 4;  // keep >= 4 chunks per split
+  if (want < 1) want = 1;
+  p.chunks_per_split = (int)((total_chunks + want - 1) / want);
+  p.nsplit = (int)((total_chunks + p.chunks_per_split - 1) / p.chunks_per_split);
+  if (p.nsplit > 1) (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
+  dim3 grid(i2r_cdiv(p.K, BN), i2r_cdiv(p.Cout, BM), p.nsplit);
+  if (ks == 3)
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 3>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, s, p);
+}
+
+extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H,
+                                    int W, int Cout, int ksize, i2r_stream_t stream) {
+  I2R_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+  I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size %d unsupported (1 or 3)", ksize);
+  I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_wgrad: non-positive dimension");
+  WgradParams p{x, dy, dw, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1};
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout <= 32)
+    launch_wgrad<1, 4, 1, 1>(p, ksize, s);
+  else if (p.K <= 32)
+    launch_wgrad<4, 1, 1, 1>(p, ksize, s);
+  else if ((long)i2r_cdiv(p.K, 128) * i2r_cdiv(Cout, 128) >= 8 && Cout > 64)
+    launch_wgrad<2, 2, 2, 2>(p, ksize, s);
+  else
+    launch_wgrad<2, 2, 1, 1>(p, ksize, s);
+  if (dbias)
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(i2r_cdiv(Cout, 4)), dim3(256), 0, s, dy, dbias, B, Cout, H * W);
+  return i2r_check_launch("conv2d_wgrad");
+}

@@ -71,6 +71,17 @@ class Conv2d(torch.nn.Module):
         f = f.ger(f).unsqueeze(0).unsqueeze(1) / f.sum().square()
         self.register_buffer('resample_filter', f if up or down else None)  # kept for state-dict compatibility
 
+    def packed_weight(self):
+        """K-major packed copy of ``weight`` for the conv kernels, re-made whenever the parameter is written
+        (``_version``), moved (``data_ptr``) or a new pack epoch starts (the sampler bumps it inside graph capture so
+        that every replay re-packs from the live weights)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, ops.pack_epoch())
+        if getattr(self, "_wp_key", None) != key:
+            self._wp = ops.conv2d_pack(w.detach())
+            self._wp_key = key
+        return self._wp
+
     def forward(self, x, residual=None):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue."""
         if self.up:
@@ -78,7 +89,7 @@ class Conv2d(torch.nn.Module):
         if self.down:
             x = ops.Down2Fn.apply(x)
         if self.weight is not None:
-            return ops.Conv2dFn.apply(x, self.weight, self.bias, residual)
+            return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight())
         if residual is not None:
             raise ValueError("residual needs a convolution to fuse into")
         return x

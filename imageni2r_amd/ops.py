@@ -40,6 +40,19 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_PACK_EPOCH = [0]
+
+
+def pack_epoch() -> int:
+    return _PACK_EPOCH[0]
+
+
+def new_pack_epoch() -> int:
+    """Invalidate every cached packed weight (used at the start of a hipGraph capture)."""
+    _PACK_EPOCH[0] += 1
+    return _PACK_EPOCH[0]
+
+
 # ======================================================================================================= raw ops
 def ts_to_img(ts, delay, embedding, cols, side, pad_value=0.0, want_mask=False):
     _chk(ts, "ts")
@@ -72,32 +85,50 @@ def img_to_ts(img, L, delay, embedding, cols):
     return ts
 
 
-def conv2d_fwd(x, w, bias=None, residual=None):
-    _chk(x, "x"); _chk(w, "w")
+def conv2d_pack(w, dgrad=False):
+    """OIHW weights -> the K-major packed layout the conv kernels read (transposed + flipped for dgrad)."""
+    _chk(w, "w")
+    Cout, Cin, k, k2 = w.shape
+    if k != k2 or k not in (1, 3):
+        raise ValueError(f"conv2d: kernel {k}x{k2} unsupported")
+    n = _lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, int(dgrad))
+    wp = torch.empty((n,), dtype=torch.float32, device=w.device)
+    _lib.call("i2r_conv2d_pack_weight_f32", _p(w), _p(wp), Cout, Cin, k, int(dgrad), _stream())
+    return wp
+
+
+def _conv_packed(x, wp, bias, residual, Cout, k):
     B, Cin, H, W = x.shape
-    Cout, Cin2, k, k2 = w.shape
-    if Cin2 != Cin or k != k2:
-        raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
-    if bias is not None:
-        _chk(bias, "bias")
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
     if residual is not None:
         _chk(residual, "residual")
         if residual.shape != out.shape:
             raise ValueError("conv2d: residual shape mismatch")
-    _lib.call("i2r_conv2d_fwd_f32", _p(x), _p(w), _p(bias), _p(residual), _p(out), B, Cin, H, W, Cout, k, _stream())
+    nsk = _lib.query("i2r_conv2d_splitk_floats", B, Cin, H, W, Cout, k)
+    ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
+    _lib.call("i2r_conv2d_fwd_packed_f32", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W,
+              Cout, k, _stream())
     return out
+
+
+def conv2d_fwd(x, w, bias=None, residual=None, wp=None):
+    """conv2d(x, w, pad=k//2) + bias + residual.  ``wp``: weights already packed by conv2d_pack (cached by Conv2d)."""
+    _chk(x, "x"); _chk(w, "w")
+    Cout, Cin2, k, k2 = w.shape
+    if Cin2 != x.shape[1] or k != k2:
+        raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    if bias is not None:
+        _chk(bias, "bias")
+    if wp is None:
+        wp = conv2d_pack(w)
+    return _conv_packed(x, wp, bias, residual, Cout, k)
 
 
 def conv2d_dgrad(dy, w):
     _chk(dy, "dy"); _chk(w, "w")
-    B, Cout, H, W = dy.shape
-    Cout2, Cin, k, _ = w.shape
-    assert Cout2 == Cout
-    ws = torch.empty(w.numel(), dtype=torch.float32, device=dy.device)
-    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    _lib.call("i2r_conv2d_dgrad_f32", _p(dy), _p(w), _p(ws), _p(dx), B, Cin, H, W, Cout, k, _stream())
-    return dx
+    Cout, Cin, k, _ = w.shape
+    assert dy.shape[1] == Cout
+    return _conv_packed(dy, conv2d_pack(w, dgrad=True), None, None, Cin, k)
 
 
 def conv2d_wgrad(x, dy, ksize, want_bias=True):
@@ -349,11 +380,11 @@ class Conv2dFn(torch.autograd.Function):
     """conv2d + bias + residual (networks.py:87-89 and the x.add_ of :178/:185)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual):
+    def forward(ctx, x, w, bias, residual, wp=None):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return conv2d_fwd(x, w, bias, None if residual is None else _c(residual))
+        return conv2d_fwd(x, w, bias, None if residual is None else _c(residual), wp)
 
     @staticmethod
     def backward(ctx, dy):
@@ -365,7 +396,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, dy, w.shape[-1], want_bias=ctx.has_bias)
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres
+        return dx, dw, db, dres, None
 
 
 class Down2Fn(torch.autograd.Function):

@@ -1,0 +1,130 @@
+"""Multi-GPU partitioning of the hot path over one 8 x MI355X node (one process per GPU, torch.distributed; the "nccl"
+backend is RCCL over xGMI on ROCm, "gloo" is used by the CPU tests).
+
+The reference has no distributed code at all; the path shards naturally in two places (§8(e)):
+
+* training: samples are independent and the loss is a mean over all elements, so with equal per-rank batches the
+  global gradient is the mean of the rank gradients -> ONE averaged all-reduce of the net gradients per step, done in
+  size-bounded buckets that are launched from autograd hooks as soon as a bucket's gradients exist, so the collectives
+  overlap the rest of backward (`GradBucketReducer`);
+* sampling: every series depends only on its own latent -> shard by noise seed, no collective except a final gather of
+  the generated series (`shard_range`, `gather_series`).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 413 MB of fp32 gradients of shape C
+moves 2*(7/8)*413 MB per GPU; buckets default to 32 MiB so RCCL can pipeline them across links while backward runs.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) of `total` items owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def gather_series(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """All-gather per-rank (n_r, L, C) series into (total, L, C) in rank order (ranks may own n or n+1 items)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    counts = [shard_range(total, r, world) for r in range(world)]
+    nmax = max(e - b for b, e in counts)
+    padded = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded = torch.cat([local, pad], dim=0)
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded.contiguous(), group=group)
+    return torch.cat([o[: e - b] for o, (b, e) in zip(out, counts)], dim=0)
+
+
+class GradBucketReducer:
+    """Bucketed, backward-overlapped gradient averaging for data-parallel training.
+
+    Parameters are walked in REVERSE registration order (the order backward produces their gradients) and packed into
+    flat buckets of at most `bucket_bytes`.  Each parameter's ``.grad`` is (re)bound to a view of its bucket, so the
+    all-reduce needs no flatten/unflatten copies; a post-accumulate-grad hook counts arrivals and launches the bucket's
+    asynchronous all-reduce when it is complete.  `finish()` waits for the outstanding collectives and divides by the
+    world size; call it after ``loss.backward()`` and before ``clip_grad_norm_`` / ``optimizer.step()`` (the clip
+    norm is then identical on every rank without another collective).
+    Works unchanged if the caller uses ``optimizer.zero_grad()`` (grads set to None): the hook re-binds the view.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.buckets: List[torch.Tensor] = []
+        self._slot = {}          # param -> (bucket index, offset)
+        self._need: List[int] = []
+        self._arrived: List[int] = []
+        self._work: List[Optional[object]] = []
+        cur: List[torch.nn.Parameter] = []
+        cur_bytes = 0
+
+        def close():
+            nonlocal cur, cur_bytes
+            if not cur:
+                return
+            n = sum(p.numel() for p in cur)
+            flat = torch.zeros(n, dtype=cur[0].dtype, device=cur[0].device)
+            off = 0
+            for p in cur:
+                self._slot[p] = (len(self.buckets), off)
+                off += p.numel()
+            self.buckets.append(flat)
+            self._need.append(len(cur))
+            self._arrived.append(0)
+            self._work.append(None)
+            cur, cur_bytes = [], 0
+
+        for p in reversed(self.params):
+            if cur and (cur_bytes + p.numel() * p.element_size() > bucket_bytes
+                        or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                close()
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+        close()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _view(self, p):
+        b, off = self._slot[p]
+        return self.buckets[b][off: off + p.numel()].view_as(p)
+
+    def _on_grad(self, p):
+        b, _ = self._slot[p]
+        view = self._view(p)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)      # first step / after zero_grad(set_to_none=True): adopt the bucket storage
+            p.grad = view
+        self._arrived[b] += 1
+        if self._arrived[b] == self._need[b] and self.world > 1:
+            self._work[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket and turn sums into means.  Buckets whose parameters got no gradient this step are
+        reduced here (as zeros for the missing ones) so all ranks issue the same collectives."""
+        for b, flat in enumerate(self.buckets):
+            if self.world > 1:
+                if self._work[b] is None:
+                    self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work[b].wait()
+                flat.div_(self.world)
+            self._work[b] = None
+            self._arrived[b] = 0
+
+    def zero_grad(self):
+        """Zero the buckets in place (keeps the views bound; cheaper than set_to_none + re-adoption)."""
+        for flat in self.buckets:
+            flat.zero_()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

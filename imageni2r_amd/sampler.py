@@ -101,7 +101,9 @@ class DiffusionProcess:
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
+                    ops.new_pack_epoch()  # weights are re-packed INSIDE the graph: replays always see live weights
                     static_out = self._loop(static_in, t_host, sig_dev)
+                ops.new_pack_epoch()      # and eager code never reuses the graph-owned packed buffers
                 entry = (graph, static_in, static_out, sig_dev)
                 self._graphs[key] = entry
             graph, static_in, static_out, _ = entry

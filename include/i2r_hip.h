@@ -2,7 +2,7 @@
  *
  * The reference (azencot-group/ImagenI2R) has no FFI: its boundary for this path is the Python object API
  * (TS2img_Karras / EDMPrecond / DiffusionProcess / DelayEmbedder).  The host-side mirror of that API lives in
- * imageni2r_amd/*.py; underneath it every arithmetic step of the path is one of the entry points below.  Each entry
+ * the imageni2r_amd Python package; underneath it every arithmetic step of the path is one of the entry points below.  Each entry
  * point cites the reference code it replaces (paths relative to the reference repository root).
  *
  * Conventions
@@ -40,14 +40,25 @@ int i2r_img_to_ts_f64(const double* img, float* ts, int B, int L, int C, int del
                       i2r_stream_t stream);
 
 /* ---- convolutions: models/networks.py:68-90 (Conv2d.forward, non-fused resample path) ----------------------------- */
-/* out = conv2d(x, w, padding = ksize/2) + bias + residual   (bias, residual may be NULL; w is OIHW; ksize 1 or 3).
- * `residual` fuses the x.add_(skip) / proj(...).add_(x) of UNetBlock.forward (:178, :185). */
-int i2r_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
-                       int Cin, int H, int W, int Cout, int ksize, i2r_stream_t stream);
-/* autograd of the above w.r.t. x: dx = conv2d(dy, flip(w)^T).  wt_ws: workspace of Cout*Cin*ksize^2 floats. */
-int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* wt_ws, float* dx, int B, int Cin, int H, int W,
-                         int Cout, int ksize, i2r_stream_t stream);
-int i2r_conv2d_weight_flip_f32(const float* w, float* wt, int Cout, int Cin, int ksize, i2r_stream_t stream);
+/* out = conv2d(x, w, padding = ksize/2) + bias + residual   (bias, residual may be NULL; ksize 1 or 3).
+ * `residual` fuses the x.add_(skip) / proj(...).add_(x) of UNetBlock.forward (:178, :185).
+ * The kernels read weights pre-packed K-major (Wp[Kpad][Cout4]); pack once per weight version: */
+long i2r_conv2d_packed_floats(int Cout, int Cin, int ksize, int dgrad);
+int i2r_conv2d_pack_weight_f32(const float* w /* OIHW */, float* wp, int Cout, int Cin, int ksize, int dgrad,
+                               i2r_stream_t stream);
+/* floats of split-K workspace this shape wants (0 = none); passing less (or NULL) only disables split-K */
+long i2r_conv2d_splitk_floats(int B, int Cin, int H, int W, int Cout, int ksize);
+int i2r_conv2d_fwd_packed_f32(const float* x, const float* wp, const float* bias, const float* residual, float* out,
+                              float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
+                              i2r_stream_t stream);
+/* same, packing w (OIHW) into ws on the fly; ws_floats >= packed_floats (+ splitk_floats to enable split-K) */
+int i2r_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* residual, float* out,
+                       float* ws, long ws_floats, int B, int Cin, int H, int W, int Cout, int ksize,
+                       i2r_stream_t stream);
+/* autograd of conv2d w.r.t. x: dx = conv2d(dy, flip(w)^T) = the forward kernel on weights packed with dgrad=1;
+ * ws_floats >= i2r_conv2d_packed_floats(Cout, Cin, ksize, 1) (+ split-K floats of the transposed problem). */
+int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* ws, long ws_floats, float* dx, int B, int Cin,
+                         int H, int W, int Cout, int ksize, i2r_stream_t stream);
 /* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) is overwritten; dbias (Cout) may be NULL. */
 int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
                          int Cout, int ksize, i2r_stream_t stream);

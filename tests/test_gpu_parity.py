@@ -189,7 +189,8 @@ def test_conv_golden(ops, name):
 @pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 128, 128, 16, 3), (2, 384, 256, 8, 3), (3, 1024, 512, 2, 3),
                                             (2, 12, 128, 16, 3), (2, 128, 12, 16, 3), (2, 256, 768, 8, 1),
                                             (5, 321, 128, 16, 3), (2, 128, 321, 16, 3), (3, 256, 256, 1, 3),
-                                            (2, 768, 256, 4, 1), (33, 64, 96, 4, 3), (1, 7, 128, 32, 3)])
+                                            (2, 768, 256, 4, 1), (33, 64, 96, 4, 3), (1, 7, 128, 32, 3),
+                                            (16, 256, 256, 4, 3), (40, 96, 160, 8, 3), (2, 13, 40, 4, 1)])
 def test_conv_shapes_vs_oracle(ops, B, Cin, Cout, H, k):
     """Every tile variant / edge (ragged Cout, ragged positions, tiny K, 1x1 spatial) of fwd, dgrad and wgrad."""
     gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
@@ -208,6 +209,41 @@ def test_conv_shapes_vs_oracle(ops, B, Cin, Cout, H, k):
     dw, db = ops.conv2d_wgrad(cu(x.numpy()), cu(dy.numpy()), k)
     assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
     assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+
+
+def test_conv_c_abi_convenience_entry_points(ops):
+    """i2r_conv2d_fwd_f32 / i2r_conv2d_dgrad_f32 (pack-on-the-fly forms) called directly through ctypes, with and
+    without room for the split-K slabs in the workspace."""
+    import ctypes
+    from imageni2r_amd import _lib
+    gen = torch.Generator().manual_seed(77)
+    B, Cin, Cout, H, k = 3, 512, 256, 2, 3
+    x = torch.randn(B, Cin, H, H, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=gen)
+    dy = torch.randn(B, Cout, H, H, generator=gen)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1)
+    xd, wd, bd, dyd = cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), cu(dy.numpy())
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pf = _lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, 0)
+    sk = _lib.query("i2r_conv2d_splitk_floats", B, Cin, H, H, Cout, k)
+    assert sk > 0  # this shape (12 positions, K = 4608) must want split-K
+    for extra in (0, sk):
+        ws = torch.empty(pf + extra, device=DEV)
+        out = torch.empty(B, Cout, H, H, device=DEV)
+        _lib.call("i2r_conv2d_fwd_f32", vp(xd), vp(wd), vp(bd), None, vp(out), vp(ws), pf + extra, B, Cin, H, H, Cout,
+                  k, st)
+        assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+    pfd = _lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, 1)
+    skd = _lib.query("i2r_conv2d_splitk_floats", B, Cout, H, H, Cin, k)
+    ws = torch.empty(pfd + skd, device=DEV)
+    dx = torch.empty(B, Cin, H, H, device=DEV)
+    _lib.call("i2r_conv2d_dgrad_f32", vp(dyd), vp(wd), vp(ws), pfd + skd, vp(dx), B, Cin, H, H, Cout, k, st)
+    assert rel_err(dx.cpu().numpy(), ref_dx.numpy()) < TOL
+    with pytest.raises(_lib.I2RError):  # workspace too small for the packed weights -> loud error
+        _lib.call("i2r_conv2d_fwd_f32", vp(xd), vp(wd), vp(bd), None, vp(out), vp(ws), 16, B, Cin, H, H, Cout, k, st)
 
 
 @pytest.mark.parametrize("heads,C,H", [(1, 64, 4), (2, 128, 8), (2, 128, 1)])
