@@ -11,6 +11,7 @@ from .delay import DelayEmbedder
 from .ema import LitEma
 from .karras import TS2img_Karras
 from .sampler import DiffusionProcess
+from .ops import conv_math, set_conv_math
 
 __all__ = ["TS2img_Karras", "EDMPrecond", "DhariwalUNet", "UNetBlock", "Conv2d", "GroupNorm", "Linear",
-           "PositionalEmbedding", "DelayEmbedder", "DiffusionProcess", "LitEma"]
+           "PositionalEmbedding", "DelayEmbedder", "DiffusionProcess", "LitEma", "conv_math", "set_conv_math"]

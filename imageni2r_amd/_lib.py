@@ -28,6 +28,10 @@ SIGNATURES = {
     "i2r_conv2d_fwd_packed_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
     "i2r_conv2d_fwd_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
     "i2r_conv2d_dgrad_f32": [P, P, P, L, P, I, I, I, I, I, I, P],
+    "i2r_conv2d_packed_h2_bytes": [I, I, I],
+    "i2r_conv2d_pack_weight_h2": [P, P, I, I, I, P],
+    "i2r_conv2d_splitk_h2_floats": [I, I, I, I, I, I],
+    "i2r_conv2d_fwd_h2": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
     "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
     "i2r_up2_f32": [P, P, L, I, I, F, P],
@@ -54,7 +58,8 @@ SIGNATURES = {
     "i2r_heun_correct_f64": [P, P, P, P, P, L, D, D, P],
 }
 
-RETURNS_LONG = {"i2r_conv2d_packed_floats", "i2r_conv2d_splitk_floats"}
+RETURNS_LONG = {"i2r_conv2d_packed_floats", "i2r_conv2d_splitk_floats", "i2r_conv2d_packed_h2_bytes",
+                "i2r_conv2d_splitk_h2_floats"}
 
 _lib = None
 

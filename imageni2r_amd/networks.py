@@ -82,6 +82,15 @@ class Conv2d(torch.nn.Module):
             self._wp_key = key
         return self._wp
 
+    def packed_weight_h2(self):
+        """Split-f16 packed copy of ``weight`` for the inference kernel (same invalidation rule as packed_weight)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, ops.pack_epoch())
+        if getattr(self, "_wph_key", None) != key:
+            self._wph = ops.conv2d_pack_h2(w.detach())
+            self._wph_key = key
+        return self._wph
+
     def forward(self, x, residual=None):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue."""
         if self.up:
@@ -89,6 +98,9 @@ class Conv2d(torch.nn.Module):
         if self.down:
             x = ops.Down2Fn.apply(x)
         if self.weight is not None:
+            if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
+                return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
+                                         None if residual is None else ops._c(residual))
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight())
         if residual is not None:
             raise ValueError("residual needs a convolution to fuse into")

@@ -41,6 +41,19 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 _PACK_EPOCH = [0]
+_CONV_MATH = ["f16x2"]  # math of INFERENCE (no-grad) conv forwards: "f16x2" (split-f16 MFMA) or "f32" (exact fp32 MFMA)
+
+
+def conv_math() -> str:
+    return _CONV_MATH[0]
+
+
+def set_conv_math(mode: str) -> None:
+    """Select the inference conv kernel: "f16x2" (default; ~1e-6 rel. error, 3-5x faster) or "f32" (exact fp32 MFMA).
+    Training (grad-enabled) forwards/backwards always use the exact fp32 kernels."""
+    if mode not in ("f16x2", "f32"):
+        raise ValueError(mode)
+    _CONV_MATH[0] = mode
 
 
 def pack_epoch() -> int:
@@ -122,6 +135,35 @@ def conv2d_fwd(x, w, bias=None, residual=None, wp=None):
     if wp is None:
         wp = conv2d_pack(w)
     return _conv_packed(x, wp, bias, residual, Cout, k)
+
+
+def conv2d_pack_h2(w):
+    """OIHW fp32 weights -> split-f16 (hi | lo, scaled 2^6) packed layout of the f16x2 inference conv kernel."""
+    _chk(w, "w")
+    Cout, Cin, k, k2 = w.shape
+    if k != k2 or k not in (1, 3):
+        raise ValueError(f"conv2d: kernel {k}x{k2} unsupported")
+    n = _lib.query("i2r_conv2d_packed_h2_bytes", Cout, Cin, k)
+    wp = torch.empty((n,), dtype=torch.uint8, device=w.device)
+    _lib.call("i2r_conv2d_pack_weight_h2", _p(w), _p(wp), Cout, Cin, k, _stream())
+    return wp
+
+
+def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None):
+    """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip)."""
+    _chk(x, "x")
+    Cout, Cin, k, _ = w_shape
+    B, Cin2, H, W = x.shape
+    if Cin2 != Cin:
+        raise ValueError("conv2d_fwd_h2: channel mismatch")
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        _chk(residual, "residual")
+    nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
+    ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
+    _lib.call("i2r_conv2d_fwd_h2", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W, Cout, k,
+              _stream())
+    return out
 
 
 def conv2d_dgrad(dy, w):

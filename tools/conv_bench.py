@@ -35,6 +35,12 @@ for sh in shapes:
     if a.op == "fwd":
         wp = ops.conv2d_pack(w)
         fn = lambda: ops.conv2d_fwd(x, w, b, None, wp)
+    elif a.op == "h2":
+        wph = ops.conv2d_pack_h2(w)
+        fn = lambda: ops.conv2d_fwd_h2(x, w.shape, wph, b, None)
+        ref = ops.conv2d_fwd(x, w, b, None)
+        err = (fn() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"   h2 vs f32 max rel err {err:.2e}")
     elif a.op == "dgrad":
         fn = lambda: ops.conv2d_dgrad(dy, w)
     else:
