@@ -61,7 +61,7 @@ int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* ws, long ws_flo
                          int H, int W, int Cout, int ksize, i2r_stream_t stream);
 /* Inference-only forward on the HALF-precision matrix cores with fp32-grade accuracy ("f16x2 split": x = hi + lo in
  * fp16, three f16 MFMAs per tile-step, fp32 accumulate; ~1e-6 relative error; requires |x| < 65504).  Same contract as
- * i2r_conv2d_fwd_packed_f32 with weights packed by i2r_conv2d_pack_weight_h2 (i2r_conv2d_packed_h2_bytes bytes). */
+ * i2r_conv2d_fwd_packed_f32 with weights packed by the h2 pack routine below (its byte count from the _bytes query). */
 long i2r_conv2d_packed_h2_bytes(int Cout, int Cin, int ksize);
 int i2r_conv2d_pack_weight_h2(const float* w /* OIHW */, void* wp, int Cout, int Cin, int ksize, i2r_stream_t stream);
 long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksize);
