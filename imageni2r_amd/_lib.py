@@ -37,22 +37,25 @@ SIGNATURES = {
     "i2r_up2_f32": [P, P, L, I, I, F, P],
     "i2r_concat_channels_f32": [P, P, P, I, L, L, P],
     "i2r_split_channels_f32": [P, P, P, I, L, L, I, P],
-    "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P],
-    "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P],
+    "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P, P],
+    "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
     "i2r_reduce_rows_f32": [P, P, I, I, P],
     "i2r_attention_fwd_f32": [P, P, P, I, I, I, P],
     "i2r_attention_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
     "i2r_pos_embedding_f32": [P, P, I, I, I, P],
     "i2r_linear_fwd_f32": [P, P, P, P, P, I, I, I, I, P],
-    "i2r_linear_bwd_f32": [P, P, P, P, P, I, I, I, P],
+    "i2r_linear_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
     "i2r_silu_bwd_f32": [P, P, P, L, P],
     "i2r_add_f32": [P, P, P, L, P],
     "i2r_edm_scale_input": [P, I, P, I, P, P, I, L, F, P],
     "i2r_edm_combine": [P, I, P, P, I, P, I, L, F, P],
     "i2r_edm_combine_bwd": [P, P, I, P, I, L, F, P],
-    "i2r_edm_noise": [P, P, P, P, P, P, P, I, L, F, F, F, U, U, P],
+    "i2r_edm_noise": [P, P, P, P, P, P, P, I, L, F, F, F, U, U, P, P],
+    "i2r_counter_add_u64": [P, U, P],
     "i2r_nan_mask_f32": [P, P, P, L, P],
     "i2r_masked_edm_loss": [P, P, P, P, P, P, P, I, I, L, P],
+    "i2r_opt_chunk_elems": [],
+    "i2r_fused_adamw_ema_step": [P, P, I, P, P, P, P, F, F, F, F, F, F, F, I, P],
     "i2r_heun_init_f64": [P, P, L, D, P],
     "i2r_heun_euler_f64": [P, P, P, P, L, D, D, P],
     "i2r_heun_correct_f64": [P, P, P, P, P, L, D, D, P],

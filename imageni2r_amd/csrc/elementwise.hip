@@ -111,8 +111,10 @@ extern "C" int i2r_edm_combine_bwd(const float* dD, const float* sigma, int nsig
 __global__ void edm_noise_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                  const float* __restrict__ rnd_in, const float* __restrict__ noise_in,
                                  float* __restrict__ xn, float* __restrict__ sigma, float* __restrict__ weight, int B,
-                                 long chw, float P_mean, float P_std, float sd, uint64_t seed, uint64_t offset) {
+                                 long chw, float P_mean, float P_std, float sd, uint64_t seed, uint64_t offset,
+                                 const uint64_t* __restrict__ rng_step) {
   long total = (long)B * chw;
+  if (rng_step) offset += rng_step[0] << 20;
   uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
   GRID_STRIDE(i, total) {
     int b = (int)(i / chw);
@@ -142,11 +144,25 @@ __global__ void edm_noise_kernel(const float* __restrict__ x, const float* __res
 
 extern "C" int i2r_edm_noise(const float* x, const float* mask, const float* rnd_in, const float* noise_in,
                              float* xn, float* sigma, float* weight, int B, long chw, float P_mean, float P_std,
-                             float sigma_data, uint64_t seed, uint64_t offset, i2r_stream_t stream) {
+                             float sigma_data, uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                             i2r_stream_t stream) {
   I2R_REQUIRE(x && mask && xn && sigma && weight, "edm_noise: null pointer");
   hipLaunchKernelGGL(edm_noise_kernel, dim3(ew_grid((long)B * chw)), dim3(256), 0, (hipStream_t)stream, x, mask,
-                     rnd_in, noise_in, xn, sigma, weight, B, chw, P_mean, P_std, sigma_data, seed, offset);
+                     rnd_in, noise_in, xn, sigma, weight, B, chw, P_mean, P_std, sigma_data, seed, offset,
+                     rng_step);
   return i2r_check_launch("edm_noise");
+}
+
+// Device-resident step counter of the training RNG streams (dropout masks, noise draws): kernels that take
+// `rng_step` add (*rng_step << 20) to their Philox offset, so a captured HIP graph draws fresh randomness on every
+// replay once this increment is part of the graph.
+__global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += inc;
+}
+extern "C" int i2r_counter_add_u64(uint64_t* counter, uint64_t inc, i2r_stream_t stream) {
+  I2R_REQUIRE(counter, "counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, inc);
+  return i2r_check_launch("counter_add");
 }
 
 // ------------------------------------------------------------------ masked EDM loss (our.py:63-66)

@@ -1,33 +1,243 @@
 // Fused GroupNorm family (models/networks.py:104-106 as used at :168, :173, :182, :460):
 //   y = dropout( act( gn(x) * (1 + scale) + shift ) )      act in {identity, SiLU}; scale/shift optional (adaptive
 //   modulation from the block's `affine` Linear, :170-173); dropout only in training (:177).
-// One wavefront owns one (sample, group): a group is (C/G)*H*W contiguous fp32 in NCHW, at most 16 KiB in every
-// shipped config, so the statistics are a wave-local shuffle reduction and the tensor makes one trip from HBM
-// (passes 2 and 3 re-read the group from L1/L2).  HBM-bound: 8 B/element forward, 16 B/element backward.
+// A group is (C/G)*H*W contiguous fp32 in NCHW, at most 16 KiB in every shipped config.  One wavefront (or a 16-lane
+// quarter of one for groups of <= 64 elements) owns one (sample, group) and keeps the whole group in REGISTERS: one
+// 16-B-per-lane read of x (and of dy in backward), shuffle reductions, one 16-B-per-lane write.  HBM-bound:
+// 8 B/element forward, 12 B/element backward (+ the small per-channel outputs).
+// Shapes the register kernels do not cover (H*W not a power of two >= 4, groups > 4096 elements) take the generic
+// strided-loop kernels at the bottom.
 #include "i2r_common.h"
 #include "../../include/i2r_hip.h"
 
 #define GN_WAVES 4
 
-__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t offset, long i, float p) {
-  uint4 r = philox4x32(make_uint4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)),
-                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-  return (u32_to_unit(r.x) > p) ? 1.0f / (1.0f - p) : 0.0f;
+// Dropout keep-mask: one Philox4x32 call covers 4 consecutive elements (counter = element index / 4).
+__device__ __forceinline__ uint4 keep_bits(uint64_t seed, uint64_t offset, long i4) {
+  return philox4x32(make_uint4((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)),
+                    make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ float keep_of(uint32_t r, float p, float inv_keep) {
+  return (u32_to_unit(r) > p) ? inv_keep : 0.0f;
+}
+__device__ __forceinline__ uint64_t eff_offset(uint64_t offset, const uint64_t* rng_step) {
+  return rng_step ? offset + (rng_step[0] << 20) : offset;
 }
 
-__global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ ss, int ss_batch, float* __restrict__ y, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, int B, int C, int HW, int G, float eps, int act, float drop_p, uint64_t seed,
-    uint64_t offset) {
+template <int LPG>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+  for (int o = LPG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over aligned runs of `w` lanes (w a power of two <= 64, wave-uniform)
+__device__ __forceinline__ float run_sum(float v, int w) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    if (o < w) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct GnP {
+  const float* x;
+  const float* gamma;
+  const float* beta;
+  const float* ss;      // [scale | shift] (ss_batch, 2C) or null
+  const float* mean_in; // backward
+  const float* rstd_in;
+  const float* dy;
+  float* y;             // forward output / backward dx
+  float* mean_out;
+  float* rstd_out;
+  float* dgb_part;      // backward: (B, 2C) per-sample [dgamma | dbeta]
+  float* dss;           // backward: (B, 2C) [dscale | dshift]
+  const uint64_t* rng_step;
+  int ss_batch, B, C, HW, G, sh, act;
+  float eps, drop_p;
+  uint64_t seed, offset;
+};
+
+// LPG lanes own one group; each lane holds NV float4 (elements (sl + LPG*k)*4 .. +3).  Requires HW = 2^sh >= 4.
+template <int LPG, int NV>
+__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
+  const int sl = threadIdx.x % LPG;
+  const long wg = (long)blockIdx.x * (256 / LPG) + threadIdx.x / LPG;
+  const bool valid = wg < (long)p.B * p.G;
+  const int b = valid ? (int)(wg / p.G) : 0, g = valid ? (int)(wg % p.G) : 0;
+  const int cpg = p.C / p.G, n = cpg * p.HW;
+  const long base = ((long)b * p.C + (long)g * cpg) * p.HW;
+  const float4* xp = reinterpret_cast<const float4*>(p.x + base);
+
+  float4 v[NV];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int i4 = sl + LPG * k;
+    v[k] = (valid && i4 * 4 < n) ? xp[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = seg_sum<LPG>(s) / (float)n;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int i4 = sl + LPG * k;
+    if (i4 * 4 < n) {
+      float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(seg_sum<LPG>(q) / (float)n + p.eps);
+  if (!valid) return;
+  if (sl == 0 && p.mean_out) {
+    p.mean_out[wg] = mean;
+    p.rstd_out[wg] = rstd;
+  }
+  const float* ssp = p.ss ? p.ss + (long)(p.ss_batch == 1 ? 0 : b) * 2 * p.C : nullptr;
+  const uint64_t off = eff_offset(p.offset, p.rng_step);
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  float4* yp = reinterpret_cast<float4*>(p.y + base);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int i4 = sl + LPG * k;
+    if (i4 * 4 >= n) continue;
+    int c = g * cpg + ((i4 * 4) >> p.sh);
+    float gm = p.gamma[c], bt = p.beta[c];
+    float u[4] = {(v[k].x - mean) * rstd * gm + bt, (v[k].y - mean) * rstd * gm + bt,
+                  (v[k].z - mean) * rstd * gm + bt, (v[k].w - mean) * rstd * gm + bt};
+    if (ssp) {
+      float sc = ssp[c] + 1.0f, shf = ssp[p.C + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = u[j] * sc + shf;
+    }
+    if (p.act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = silu_f(u[j]);
+    }
+    if (p.drop_p > 0.0f) {
+      uint4 r = keep_bits(p.seed, off, base / 4 + i4);
+      u[0] *= keep_of(r.x, p.drop_p, inv_keep);
+      u[1] *= keep_of(r.y, p.drop_p, inv_keep);
+      u[2] *= keep_of(r.z, p.drop_p, inv_keep);
+      u[3] *= keep_of(r.w, p.drop_p, inv_keep);
+    }
+    yp[i4] = make_float4(u[0], u[1], u[2], u[3]);
+  }
+}
+
+// Backward, same ownership.  Per-channel sums (dgamma/dbeta partials, dscale/dshift) are reductions over runs of
+// min(LPG, HW/4) lanes, accumulated over the HW/(4*LPG) register slots a channel spans when HW > 4*LPG.
+template <int LPG, int NV>
+__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
+  const int sl = threadIdx.x % LPG;
+  const long wg = (long)blockIdx.x * (256 / LPG) + threadIdx.x / LPG;
+  const bool valid = wg < (long)p.B * p.G;
+  const int b = valid ? (int)(wg / p.G) : 0, g = valid ? (int)(wg % p.G) : 0;
+  const int cpg = p.C / p.G, n = cpg * p.HW;
+  const long base = ((long)b * p.C + (long)g * cpg) * p.HW;
+  const float4* xp = reinterpret_cast<const float4*>(p.x + base);
+  const float4* dyp = reinterpret_cast<const float4*>(p.dy + base);
+  const float mean = valid ? p.mean_in[wg] : 0.0f, rstd = valid ? p.rstd_in[wg] : 0.0f;
+  const float* ssp = p.ss ? p.ss + (long)(p.ss_batch == 1 ? 0 : b) * 2 * p.C : nullptr;
+  const uint64_t off = eff_offset(p.offset, p.rng_step);
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const int q4 = p.HW >> 2;                    // float4 per channel
+  const int runw = q4 < LPG ? q4 : LPG;        // lanes of one slot that share a channel
+  const int spc = q4 <= LPG ? 1 : q4 / LPG;    // slots per channel
+
+  float4 xh[NV], dn[NV];  // xhat and d(loss)/d(normalised*gamma+beta) after modulation  (dn = du * (1+scale))
+  float S1 = 0.0f, S2 = 0.0f;
+  float a_du = 0.0f, a_dun = 0.0f, a_dn = 0.0f, a_dnx = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int i4 = sl + LPG * k;
+    bool in = valid && i4 * 4 < n;
+    int c = g * cpg + ((i4 * 4) >> p.sh);
+    float gm = 0.0f, bt = 0.0f, sc1 = 1.0f, shf = 0.0f;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
+    if (in) {
+      xv = xp[i4];
+      dv = dyp[i4];
+      gm = p.gamma[c];
+      bt = p.beta[c];
+      if (ssp) {
+        sc1 = ssp[c] + 1.0f;
+        shf = ssp[p.C + c];
+      }
+    }
+    float xs[4] = {xv.x, xv.y, xv.z, xv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
+    if (in && p.drop_p > 0.0f) {
+      uint4 r = keep_bits(p.seed, off, base / 4 + i4);
+      du[0] *= keep_of(r.x, p.drop_p, inv_keep);
+      du[1] *= keep_of(r.y, p.drop_p, inv_keep);
+      du[2] *= keep_of(r.z, p.drop_p, inv_keep);
+      du[3] *= keep_of(r.w, p.drop_p, inv_keep);
+    }
+    float xo[4], dno[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float h = (xs[j] - mean) * rstd;
+      float nn = h * gm + bt;
+      float d = du[j];
+      if (p.act) d *= dsilu_f(nn * sc1 + shf);
+      float dnj = d * sc1;
+      if (!in) { h = 0.0f; d = 0.0f; dnj = 0.0f; nn = 0.0f; }
+      xo[j] = h;
+      dno[j] = dnj;
+      a_du += d;
+      a_dun += d * nn;
+      a_dn += dnj;
+      a_dnx += dnj * h;
+    }
+    xh[k] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    dn[k] = make_float4(dno[0] * gm, dno[1] * gm, dno[2] * gm, dno[3] * gm);  // now d/dxhat
+    if ((k + 1) % spc == 0 || k == NV - 1) {  // channel complete in this lane's slots (spc, NV powers of two)
+      float r_dn = run_sum(a_dn, runw), r_dnx = run_sum(a_dnx, runw);
+      S1 += gm * a_dn;
+      S2 += gm * a_dnx;
+      if (ssp) {
+        float r_du = run_sum(a_du, runw), r_dun = run_sum(a_dun, runw);
+        if (in && (sl & (runw - 1)) == 0) {
+          p.dss[(long)b * 2 * p.C + c] = r_dun;
+          p.dss[(long)b * 2 * p.C + p.C + c] = r_du;
+        }
+      }
+      if (in && (sl & (runw - 1)) == 0) {
+        p.dgb_part[(long)b * 2 * p.C + c] = r_dnx;
+        p.dgb_part[(long)b * 2 * p.C + p.C + c] = r_dn;
+      }
+      a_du = a_dun = a_dn = a_dnx = 0.0f;
+    }
+  }
+  const float inv_n = 1.0f / (float)n;
+  const float m1 = seg_sum<LPG>(S1) * inv_n, m2 = seg_sum<LPG>(S2) * inv_n;
+  if (!valid) return;
+  float4* dxp = reinterpret_cast<float4*>(p.y + base);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int i4 = sl + LPG * k;
+    if (i4 * 4 >= n) continue;
+    dxp[i4] = make_float4(rstd * (dn[k].x - m1 - xh[k].x * m2), rstd * (dn[k].y - m1 - xh[k].y * m2),
+                          rstd * (dn[k].z - m1 - xh[k].z * m2), rstd * (dn[k].w - m1 - xh[k].w * m2));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- generic fallbacks
+__device__ __forceinline__ float keep_scale1(uint64_t seed, uint64_t offset, long i, float p) {
+  uint4 r = keep_bits(seed, offset, i >> 2);
+  uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+  return keep_of(w, p, 1.0f / (1.0f - p));
+}
+
+__global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_fwd_kernel(GnP p) {
   int lane = threadIdx.x & 63;
   long wg = (long)blockIdx.x * GN_WAVES + (threadIdx.x >> 6);  // (b, g) index, wave-uniform
-  if (wg >= (long)B * G) return;
-  int b = (int)(wg / G), g = (int)(wg % G);
-  int cpg = C / G;
+  if (wg >= (long)p.B * p.G) return;
+  int b = (int)(wg / p.G), g = (int)(wg % p.G);
+  int cpg = p.C / p.G, HW = p.HW, C = p.C;
   int n = cpg * HW;
   long base = ((long)b * C + (long)g * cpg) * HW;
-  const float* xp = x + base;
+  const float* xp = p.x + base;
+  const uint64_t off = eff_offset(p.offset, p.rng_step);
 
   float s = 0.0f;
   for (int i = lane; i < n; i += 64) s += xp[i];
@@ -37,56 +247,52 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_fwd_kernel(
     float d = xp[i] - mean;
     v += d * d;
   }
-  float rstd = 1.0f / sqrtf(wave_sum(v) / (float)n + eps);
-  if (lane == 0 && mean_out) {
-    mean_out[wg] = mean;
-    rstd_out[wg] = rstd;
+  float rstd = 1.0f / sqrtf(wave_sum(v) / (float)n + p.eps);
+  if (lane == 0 && p.mean_out) {
+    p.mean_out[wg] = mean;
+    p.rstd_out[wg] = rstd;
   }
-  const float* ssp = ss ? ss + (long)(ss_batch == 1 ? 0 : b) * 2 * C : nullptr;
+  const float* ssp = p.ss ? p.ss + (long)(p.ss_batch == 1 ? 0 : b) * 2 * C : nullptr;
   for (int i = lane; i < n; i += 64) {
     int c = g * cpg + i / HW;
-    float u = (xp[i] - mean) * rstd * gamma[c] + beta[c];
+    float u = (xp[i] - mean) * rstd * p.gamma[c] + p.beta[c];
     if (ssp) u = u * (ssp[c] + 1.0f) + ssp[C + c];
-    if (act) u = silu_f(u);
-    if (drop_p > 0.0f) u *= keep_scale(seed, offset, base + i, drop_p);
-    y[base + i] = u;
+    if (p.act) u = silu_f(u);
+    if (p.drop_p > 0.0f) u *= keep_scale1(p.seed, off, base + i, p.drop_p);
+    p.y[base + i] = u;
   }
 }
 
-// Backward.  Pass A: per-channel sums over HW of dn and dn*xhat (these are the per-sample dbeta/dgamma partials, and
-// combined with gamma they give the two group moments that dx needs); pass B: dx.
-__global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ ss, int ss_batch, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma_part,
-    float* __restrict__ dbeta_part, float* __restrict__ dss, int B, int C, int HW, int G, int act, float drop_p,
-    uint64_t seed, uint64_t offset) {
+// Pass A: per-channel sums over HW of dn and dn*xhat (the per-sample dbeta/dgamma partials; combined with gamma they
+// give the two group moments that dx needs); pass B: dx.
+__global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(GnP p) {
   int lane = threadIdx.x & 63;
   long wg = (long)blockIdx.x * GN_WAVES + (threadIdx.x >> 6);
-  if (wg >= (long)B * G) return;
-  int b = (int)(wg / G), g = (int)(wg % G);
-  int cpg = C / G;
+  if (wg >= (long)p.B * p.G) return;
+  int b = (int)(wg / p.G), g = (int)(wg % p.G);
+  int cpg = p.C / p.G, HW = p.HW, C = p.C;
   int n = cpg * HW;
   long base = ((long)b * C + (long)g * cpg) * HW;
-  const float* xp = x + base;
-  const float* dyp = dy + base;
-  float mean = mean_in[wg], rstd = rstd_in[wg];
-  const float* ssp = ss ? ss + (long)(ss_batch == 1 ? 0 : b) * 2 * C : nullptr;
+  const float* xp = p.x + base;
+  const float* dyp = p.dy + base;
+  float mean = p.mean_in[wg], rstd = p.rstd_in[wg];
+  const float* ssp = p.ss ? p.ss + (long)(p.ss_batch == 1 ? 0 : b) * 2 * C : nullptr;
+  const uint64_t off = eff_offset(p.offset, p.rng_step);
 
   float S1 = 0.0f, S2 = 0.0f;  // sum_c gamma_c * sum_hw dn,  sum_c gamma_c * sum_hw dn*xhat
   for (int cc = 0; cc < cpg; ++cc) {
     int c = g * cpg + cc;
-    float gm = gamma[c], bt = beta[c];
+    float gm = p.gamma[c], bt = p.beta[c];
     float sc1 = ssp ? ssp[c] + 1.0f : 1.0f, sh = ssp ? ssp[C + c] : 0.0f;
     float a_du = 0.0f, a_dun = 0.0f, a_dn = 0.0f, a_dnx = 0.0f;
-    for (int p = lane; p < HW; p += 64) {
-      int i = cc * HW + p;
+    for (int q = lane; q < HW; q += 64) {
+      int i = cc * HW + q;
       float xh = (xp[i] - mean) * rstd;
       float nn = xh * gm + bt;
       float u = nn * sc1 + sh;
       float du = dyp[i];
-      if (drop_p > 0.0f) du *= keep_scale(seed, offset, base + i, drop_p);
-      if (act) du *= dsilu_f(u);
+      if (p.drop_p > 0.0f) du *= keep_scale1(p.seed, off, base + i, p.drop_p);
+      if (p.act) du *= dsilu_f(u);
       float dn = du * sc1;
       a_du += du;
       a_dun += du * nn;
@@ -98,11 +304,11 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(
     a_dn = wave_sum(a_dn);
     a_dnx = wave_sum(a_dnx);
     if (lane == 0) {
-      dgamma_part[(long)b * C + c] = a_dnx;
-      dbeta_part[(long)b * C + c] = a_dn;
-      if (dss) {
-        dss[(long)b * 2 * C + c] = a_dun;      // d scale
-        dss[(long)b * 2 * C + C + c] = a_du;   // d shift
+      p.dgb_part[(long)b * 2 * C + c] = a_dnx;
+      p.dgb_part[(long)b * 2 * C + C + c] = a_dn;
+      if (p.dss) {
+        p.dss[(long)b * 2 * C + c] = a_dun;      // d scale
+        p.dss[(long)b * 2 * C + C + c] = a_du;   // d shift
       }
     }
     S1 += gm * a_dn;
@@ -112,17 +318,17 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(
   float m1 = S1 * inv_n, m2 = S2 * inv_n;
   for (int i = lane; i < n; i += 64) {
     int c = g * cpg + i / HW;
-    float gm = gamma[c];
+    float gm = p.gamma[c];
     float sc1 = ssp ? ssp[c] + 1.0f : 1.0f;
     float xh = (xp[i] - mean) * rstd;
     float du = dyp[i];
-    if (drop_p > 0.0f) du *= keep_scale(seed, offset, base + i, drop_p);
-    if (act) {
-      float u = (xh * gm + beta[c]) * sc1 + (ssp ? ssp[C + c] : 0.0f);
+    if (p.drop_p > 0.0f) du *= keep_scale1(p.seed, off, base + i, p.drop_p);
+    if (p.act) {
+      float u = (xh * gm + p.beta[c]) * sc1 + (ssp ? ssp[C + c] : 0.0f);
       du *= dsilu_f(u);
     }
     float dxh = du * sc1 * gm;
-    dx[base + i] = rstd * (dxh - m1 - xh * m2);
+    p.y[base + i] = rstd * (dxh - m1 - xh * m2);
   }
 }
 
@@ -135,35 +341,79 @@ __global__ void reduce_rows_kernel(const float* __restrict__ in, float* __restri
   out[c] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------ host side
+static int pow2_shift(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+template <bool BWD>
+static void gn_launch(const GnP& p, hipStream_t s) {
+  const long groups = (long)p.B * p.G;
+  const int n = (p.C / p.G) * p.HW;
+  const bool reg_ok = p.sh >= 2 && n <= 4096 && (((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.y) & 15) == 0 &&
+                      (!BWD || (((uintptr_t)p.dy) & 15) == 0);
+#define GN_GO(LPG, NV)                                                                                          \
+  do {                                                                                                          \
+    dim3 grid(i2r_cdiv(groups, 256 / LPG));                                                                     \
+    if (BWD)                                                                                                    \
+      hipLaunchKernelGGL((gn_bwd_reg_kernel<LPG, NV>), grid, dim3(256), 0, s, p);                               \
+    else                                                                                                        \
+      hipLaunchKernelGGL((gn_fwd_reg_kernel<LPG, NV>), grid, dim3(256), 0, s, p);                               \
+  } while (0)
+  if (!reg_ok) {
+    dim3 grid(i2r_cdiv(groups, GN_WAVES));
+    if (BWD)
+      hipLaunchKernelGGL(groupnorm_bwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
+    else
+      hipLaunchKernelGGL(groupnorm_fwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
+  } else if (n <= 64) {
+    GN_GO(16, 1);
+  } else if (n <= 256) {
+    GN_GO(64, 1);
+  } else if (n <= 512) {
+    GN_GO(64, 2);
+  } else if (n <= 1024) {
+    GN_GO(64, 4);
+  } else if (n <= 2048) {
+    GN_GO(64, 8);
+  } else {
+    GN_GO(64, 16);
+  }
+#undef GN_GO
+}
+
 extern "C" int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* ss,
                                      int ss_batch, float* y, float* mean, float* rstd, int B, int C, int HW, int G,
                                      float eps, int act, float drop_p, uint64_t seed, uint64_t offset,
-                                     i2r_stream_t stream) {
+                                     const uint64_t* rng_step, i2r_stream_t stream) {
   I2R_REQUIRE(x && gamma && beta && y, "groupnorm_fwd: null pointer");
   I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_fwd: C=%d not divisible by G=%d", C, G);
   I2R_REQUIRE((mean == nullptr) == (rstd == nullptr), "groupnorm_fwd: mean and rstd must both be given or both null");
   I2R_REQUIRE(!ss || ss_batch == 1 || ss_batch == B, "groupnorm_fwd: scale/shift batch %d vs %d", ss_batch, B);
   I2R_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "groupnorm_fwd: dropout p out of range");
-  long waves = (long)B * G;
-  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(i2r_cdiv(waves, GN_WAVES)), dim3(64 * GN_WAVES), 0,
-                     (hipStream_t)stream, x, gamma, beta, ss, ss_batch, y, mean, rstd, B, C, HW, G, eps, act, drop_p,
-                     seed, offset);
+  GnP p{};
+  p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.y = y; p.mean_out = mean; p.rstd_out = rstd;
+  p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B; p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW);
+  p.act = act; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  gn_launch<false>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_fwd");
 }
 
 extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss,
                                      int ss_batch, const float* mean, const float* rstd, const float* dy, float* dx,
-                                     float* dgamma_part, float* dbeta_part, float* dss, int B, int C, int HW, int G,
-                                     int act, float drop_p, uint64_t seed, uint64_t offset, i2r_stream_t stream) {
-  I2R_REQUIRE(x && gamma && beta && mean && rstd && dy && dx && dgamma_part && dbeta_part,
-              "groupnorm_bwd: null pointer");
+                                     float* dgb_part, float* dss, int B, int C, int HW, int G, int act, float drop_p,
+                                     uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream) {
+  I2R_REQUIRE(x && gamma && beta && mean && rstd && dy && dx && dgb_part, "groupnorm_bwd: null pointer");
   I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_bwd: C=%d not divisible by G=%d", C, G);
   I2R_REQUIRE(!ss || ss_batch == B, "groupnorm_bwd: scale/shift must be per-sample (batch %d vs %d)", ss_batch, B);
   I2R_REQUIRE((ss != nullptr) == (dss != nullptr), "groupnorm_bwd: dss must be given iff ss is");
-  long waves = (long)B * G;
-  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(i2r_cdiv(waves, GN_WAVES)), dim3(64 * GN_WAVES), 0,
-                     (hipStream_t)stream, x, gamma, beta, ss, ss_batch, mean, rstd, dy, dx, dgamma_part, dbeta_part,
-                     dss, B, C, HW, G, act, drop_p, seed, offset);
+  GnP p{};
+  p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.mean_in = mean; p.rstd_in = rstd; p.dy = dy; p.y = dx;
+  p.dgb_part = dgb_part; p.dss = dss; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B; p.C = C; p.HW = HW;
+  p.G = G; p.sh = pow2_shift(HW); p.act = act; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  gn_launch<true>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_bwd");
 }
 

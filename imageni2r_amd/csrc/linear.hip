@@ -1,82 +1,114 @@
 // Small dense layers of the noise-embedding path (models/networks.py:39-43 used at :440-447 and :170):
-// map_layer0/1 and the 36 per-block `affine` projections.  Rows = batch (1 in sampling, B in training), so these
-// are GEMV-shaped and bound by reading the weight matrix once: one wavefront streams one weight row, keeps it in
-// registers and applies it to every batch row (weight-stationary), wave-shuffle reduction per output.
+// map_layer0/1 and the 36 per-block `affine` projections, forward and backward.  Rows = batch (1 in sampling, the
+// training batch otherwise), K, N <= 2048: a few MFLOP each, so what matters is latency, not throughput.
+//
+// One kernel serves the three products (y = x W^T, dx = dy W, dW = dy^T x) through operand strides:
+//     C[i][j] = sum_k A(i,k) * B(j,k),   A(i,k) = A[i*a_rs + k*a_ks],   B(j,k) = B[j*b_rs + k*b_ks]
+// A workgroup owns one 32x32 output tile; its 4 wavefronts split the contraction range, each running a chain of exact
+// fp32 MFMAs (v_mfma_f32_32x32x2_f32, operands straight from global memory: 16-B loads along a unit-stride
+// contraction, 128-B coalesced row segments otherwise), then the four partial tiles are summed through LDS in a fixed
+// order (deterministic) and the epilogue adds the bias, keeps the pre-activation for backward and applies SiLU.
 #include "i2r_common.h"
 #include "../../include/i2r_hip.h"
 
-#define LIN_MAXK_PER_LANE 32  // K <= 2048
+struct GemmP {
+  const float* A;
+  const float* B;
+  const float* bias;   // per output column j (may be null)
+  float* C;            // (M, N) row-major, leading dimension N
+  float* pre;          // optional copy of C before the activation
+  float* rowsum;       // optional: rowsum[i] = sum_k A(i,k)   (bias gradient of the dW product)
+  int M, N, K;
+  long a_rs, a_ks, b_rs, b_ks;
+  int act;
+};
 
-// y[m][n] = act( sum_k x[m][k] * w[n][k] + b[n] );  pre[m][n] (optional) keeps the pre-activation for backward
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                         float* __restrict__ pre, int M, int K, int N, int act) {
-  int lane = threadIdx.x & 63;
-  int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;  // wave-uniform
-  float wr[LIN_MAXK_PER_LANE];
-  int nk = (K + 63) / 64;
+__device__ __forceinline__ void load4(const float* base, long rs, long ks, int idx, int lim, int k, int kend, bool vec,
+                                      float (&v)[4]) {
+  const bool ok = idx < lim;
+  if (vec && ok && k + 3 < kend) {
+    float4 t = *reinterpret_cast<const float4*>(base + (long)idx * rs + k);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
 #pragma unroll
-  for (int j = 0; j < LIN_MAXK_PER_LANE; ++j) {
-    int k = j * 64 + lane;
-    wr[j] = (j < nk && k < K) ? w[(long)n * K + k] : 0.0f;
-  }
-  float bn = bias ? bias[n] : 0.0f;
-  for (int m = 0; m < M; ++m) {
-    const float* xr = x + (long)m * K;
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LIN_MAXK_PER_LANE; ++j) {
-      int k = j * 64 + lane;
-      if (j < nk && k < K) acc += xr[k] * wr[j];
-    }
-    acc = wave_sum(acc) + bn;
-    if (lane == 0) {
-      if (pre) pre[(long)m * N + n] = acc;
-      y[(long)m * N + n] = act ? silu_f(acc) : acc;
-    }
+    for (int j = 0; j < 4; ++j) v[j] = (ok && k + j < kend) ? base[(long)idx * rs + (long)(k + j) * ks] : 0.0f;
   }
 }
 
-// dx[m][k] = sum_n dy[m][n] * w[n][k]
-__global__ void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                 int M, int K, int N) {
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= (long)M * K) return;
-  int k = (int)(i % K), m = (int)(i / K);
-  const float* dyr = dy + (long)m * N;
-  float acc = 0.0f;
-  for (int n = 0; n < N; ++n) acc += dyr[n] * w[(long)n * K + k];
-  dx[i] = acc;
+__global__ __launch_bounds__(256) void small_gemm_kernel(GemmP p, int vecA, int vecB) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  int kc = (p.K + 3) / 4;
+  kc = (kc + 7) & ~7;  // contraction slice per wave, multiple of the 8-deep step
+  const int kbeg = wave * kc;
+  int kend = kbeg + kc;
+  if (kend > p.K) kend = p.K;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  // step of 8: MFMA jj pairs A's and B's slot h with contraction index k0 + 4h + jj
+  for (int k0 = kbeg; k0 < kend; k0 += 8) {
+    float a[4], b[4];
+    load4(p.A, p.a_rs, p.a_ks, i0 + l31, p.M, k0 + 4 * h, kend, vecA, a);
+    load4(p.B, p.b_rs, p.b_ks, j0 + l31, p.N, k0 + 4 * h, kend, vecB, b);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b[jj], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int idx = tid + 256 * q;
+    int r = idx >> 5, c = idx & 31;
+    int i = i0 + r, j = j0 + c;
+    if (i < p.M && j < p.N) {
+      float v = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+      if (p.bias) v += p.bias[j];
+      long o = (long)i * p.N + j;
+      if (p.pre) p.pre[o] = v;
+      p.C[o] = p.act ? silu_f(v) : v;
+    }
+  }
+  if (p.rowsum && blockIdx.x == 0 && tid < 32 && i0 + tid < p.M) {
+    float s = 0.0f;
+    for (int k = 0; k < p.K; ++k) s += p.A[(long)(i0 + tid) * p.a_rs + (long)k * p.a_ks];
+    p.rowsum[i0 + tid] = s;
+  }
 }
-// dw[n][k] = sum_m dy[m][n] * x[m][k]
-__global__ void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                 int M, int K, int N) {
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= (long)N * K) return;
-  int k = (int)(i % K), n = (int)(i / K);
-  float acc = 0.0f;
-  for (int m = 0; m < M; ++m) acc += dy[(long)m * N + n] * x[(long)m * K + k];
-  dw[i] = acc;
+
+static bool vec_ok(const float* ptr, long rs, long ks) {
+  return ks == 1 && (rs % 4) == 0 && (((uintptr_t)ptr) & 15) == 0;
+}
+
+static void launch_gemm(const GemmP& p, hipStream_t s) {
+  dim3 grid(i2r_cdiv(p.N, 32), i2r_cdiv(p.M, 32));
+  hipLaunchKernelGGL(small_gemm_kernel, grid, dim3(256), 0, s, p, (int)vec_ok(p.A, p.a_rs, p.a_ks),
+                     (int)vec_ok(p.B, p.b_rs, p.b_ks));
 }
 
 extern "C" int i2r_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, float* pre, int M,
                                   int K, int N, int act_silu, i2r_stream_t stream) {
   I2R_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, "linear_fwd: bad argument");
-  I2R_REQUIRE(K <= 64 * LIN_MAXK_PER_LANE, "linear_fwd: in_features %d > %d unsupported", K, 64 * LIN_MAXK_PER_LANE);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(i2r_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, pre,
-                     M, K, N, act_silu);
+  GemmP p{x, w, bias, y, pre, nullptr, M, N, K, K, 1, K, 1, act_silu};
+  launch_gemm(p, (hipStream_t)stream);
   return i2r_check_launch("linear_fwd");
 }
 
-extern "C" int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, int M,
-                                  int K, int N, i2r_stream_t stream) {
+// dx (M,K) = dy (M,N) . W (N,K);   dW (N,K) = dy^T . x;   db (N) = column sums of dy   (each optional)
+extern "C" int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                  int M, int K, int N, i2r_stream_t stream) {
   I2R_REQUIRE(x && w && dy && M > 0 && K > 0 && N > 0, "linear_bwd: bad argument");
-  if (dx)
-    hipLaunchKernelGGL(linear_dx_kernel, dim3(i2r_cdiv((long)M * K, 256)), dim3(256), 0, (hipStream_t)stream, dy, w,
-                       dx, M, K, N);
-  if (dw)
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(i2r_cdiv((long)N * K, 256)), dim3(256), 0, (hipStream_t)stream, dy, x,
-                       dw, M, K, N);
+  I2R_REQUIRE(!db || dw, "linear_bwd: the bias gradient is produced together with the weight gradient");
+  if (dx) {
+    GemmP p{dy, w, nullptr, dx, nullptr, nullptr, M, K, N, N, 1, 1, K, 0};
+    launch_gemm(p, (hipStream_t)stream);
+  }
+  if (dw) {
+    GemmP p{dy, x, nullptr, dw, nullptr, db, N, K, M, 1, N, 1, K, 0};
+    launch_gemm(p, (hipStream_t)stream);
+  }
   return i2r_check_launch("linear_bwd");
 }

@@ -30,6 +30,11 @@ class LitEma(nn.Module):
         return [(shadow[self.m_name2s_name[k]], p) for k, p in model.named_parameters() if p.requires_grad]
 
     def forward(self, model):
+        if getattr(self, "fused_into_optimizer", False):
+            return  # FusedAdamW.step() already advanced the shadow weights in its own kernel
+        return self._update(model)
+
+    def _update(self, model):
         """One EMA step (:26-47): copy while num_updates <= warmup, else s -= (1 - decay) * (s - p) with
         decay = min(0.9999, (1 + n) / (10 + n)) evaluated in fp32 like the reference's 0-dim tensors."""
         if self._n is None:
@@ -53,13 +58,17 @@ class LitEma(nn.Module):
                 torch._foreach_copy_(shadows, params)
 
     def copy_to(self, model):
+        from . import ops
         with torch.no_grad():
             for s, p in self._pairs(model):
                 p.data.copy_(s.data)
+        ops.new_pack_epoch()  # .data writes do not bump _version: drop every cached packed conv weight
 
     def store(self, parameters):
         self.collected_params = [param.clone() for param in parameters]
 
     def restore(self, parameters):
+        from . import ops
         for c_param, param in zip(self.collected_params, parameters):
             param.data.copy_(c_param.data)
+        ops.new_pack_epoch()

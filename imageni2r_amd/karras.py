@@ -83,8 +83,10 @@ class TS2img_Karras(nn.Module):
             raise NotImplementedError("augment_pipe / labels are never passed by ImagenI2R")
         rnd, noise = self._injected if self._injected is not None else (None, None)
         seed = torch.initial_seed() & ((1 << 63) - 1)
+        step = ops.rng_step()
         xn, sigma, weight = ops.edm_noise(x.detach().contiguous(), mask, self.P_mean, self.P_std, self.sigma_data,
-                                          rnd=rnd, noise=noise, seed=seed, offset=next(_noise_counter))
+                                          rnd=rnd, noise=noise, seed=seed,
+                                          offset=0 if step is not None else next(_noise_counter), step=step)
         D_yn = self.net(xn, sigma)
         return D_yn, weight.reshape(-1, 1, 1, 1)
 

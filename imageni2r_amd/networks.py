@@ -18,6 +18,7 @@ import torch
 from . import ops
 
 _dropout_counter = itertools.count(1)
+_layer_ids = itertools.count(1)
 
 
 def weight_init(shape, mode, fan_in, fan_out):
@@ -114,12 +115,15 @@ class GroupNorm(torch.nn.Module):
         self.eps = eps
         self.weight = torch.nn.Parameter(torch.ones(num_channels))
         self.bias = torch.nn.Parameter(torch.zeros(num_channels))
+        self._rng_id = next(_layer_ids)  # fixed Philox stream id of this layer's dropout (device-step RNG mode)
 
     def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0):
         """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer."""
         seed = offset = 0
         if drop_p > 0.0:
-            seed, offset = torch.initial_seed() & ((1 << 63) - 1), next(_dropout_counter)
+            seed = torch.initial_seed() & ((1 << 63) - 1)
+            # host counter per call, or (device step counter, fixed layer id) when a graph owns the RNG step
+            offset = self._rng_id if ops.rng_step() is not None else next(_dropout_counter)
         return ops.GroupNormFn.apply(x, self.weight, self.bias, scale_shift, self.num_groups, self.eps, act_silu,
                                      drop_p, seed, offset)
 
@@ -243,6 +247,9 @@ class DhariwalUNet(torch.nn.Module):
                                                                 attention=(res in attn_resolutions), **block_kwargs)
         self.out_norm = GroupNorm(num_channels=cout)
         self.out_conv = Conv2d(in_channels=cout, out_channels=out_channels, kernel=3, **init_zero)
+        # dropout stream ids depend only on the position inside this network (same model => same masks per step)
+        for i, mod in enumerate(m for m in self.modules() if isinstance(m, GroupNorm)):
+            mod._rng_id = i + 1
 
     def embed(self, noise_labels):
         """Noise-level embedding (:437-447): posemb -> Linear+SiLU -> Linear+SiLU."""

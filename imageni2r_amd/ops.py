@@ -56,6 +56,26 @@ def set_conv_math(mode: str) -> None:
     _CONV_MATH[0] = mode
 
 
+_RNG_STEP = [None]  # device uint64 step counter of the training RNG streams (set by GraphedTrainStep), or None
+
+
+def rng_step():
+    return _RNG_STEP[0]
+
+
+def set_rng_step(counter) -> None:
+    """Route every training RNG stream (dropout masks, sigma / noise draws) through a device-resident step counter:
+    Philox offset = the call site's fixed id + (counter << 20).  ``None`` restores host-side offsets."""
+    if counter is not None:
+        if counter.dtype != torch.int64 or counter.numel() != 1 or not counter.is_cuda:
+            raise TypeError("rng step counter must be a 1-element int64 HIP tensor")
+    _RNG_STEP[0] = counter
+
+
+def counter_add(counter, inc=1):
+    _lib.call("i2r_counter_add_u64", _p(counter), int(inc), _stream())
+
+
 def pack_epoch() -> int:
     return _PACK_EPOCH[0]
 
@@ -217,7 +237,8 @@ def split_channels(x, C1):
     return a, c
 
 
-def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=False, drop_p=0.0, seed=0, offset=0):
+def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=False, drop_p=0.0, seed=0, offset=0,
+                  step=None):
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
@@ -233,24 +254,22 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=Fa
         mean = torch.empty((B * groups,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
     _lib.call("i2r_groupnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), ss_batch, _p(y), _p(mean), _p(rstd), B, C,
-              HW, groups, float(eps), int(bool(act)), float(drop_p), int(seed), int(offset), _stream())
+              HW, groups, float(eps), int(bool(act)), float(drop_p), int(seed), int(offset), _p(step), _stream())
     return y, mean, rstd
 
 
-def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0):
+def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0, step=None):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     _chk(dy, "dy")
     dx = torch.empty_like(x)
-    part = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+    part = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)  # per-sample [dgamma | dbeta]
     dss = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device) if ss is not None else None
     _lib.call("i2r_groupnorm_bwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0], _p(mean),
-              _p(rstd), _p(dy), _p(dx), _p(part[0]), _p(part[1]), _p(dss), B, C, HW, groups, int(bool(act)),
-              float(drop_p), int(seed), int(offset), _stream())
+              _p(rstd), _p(dy), _p(dx), _p(part), _p(dss), B, C, HW, groups, int(bool(act)),
+              float(drop_p), int(seed), int(offset), _p(step), _stream())
     dgb = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
-    # part viewed as (B, 2, C) would interleave; reduce each half separately
-    _lib.call("i2r_reduce_rows_f32", _p(part[0]), _p(dgb[:C]), B, C, _stream())
-    _lib.call("i2r_reduce_rows_f32", _p(part[1]), _vp(dgb.data_ptr() + 4 * C), B, C, _stream())
+    _lib.call("i2r_reduce_rows_f32", _p(part), _p(dgb), B, 2 * C, _stream())
     return dx, dgb[:C], dgb[C:], dss
 
 
@@ -296,13 +315,14 @@ def linear_fwd(x, w, bias=None, act=False, save_pre=False):
     return y, pre
 
 
-def linear_bwd(x, w, dy, need_dx=True, need_dw=True):
+def linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=False):
     M, K = x.shape
     N = w.shape[0]
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty_like(w) if need_dw else None
-    _lib.call("i2r_linear_bwd_f32", _p(x), _p(w), _p(dy), _p(dx), _p(dw), M, K, N, _stream())
-    return dx, dw
+    dw = torch.empty_like(w) if (need_dw or need_db) else None
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    _lib.call("i2r_linear_bwd_f32", _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), M, K, N, _stream())
+    return dx, dw, db
 
 
 def silu_bwd(pre, dy):
@@ -363,7 +383,7 @@ def edm_combine_bwd(dD, sigma, sigma_data):
     return dF
 
 
-def edm_noise(x, mask, P_mean, P_std, sigma_data, rnd=None, noise=None, seed=0, offset=0):
+def edm_noise(x, mask, P_mean, P_std, sigma_data, rnd=None, noise=None, seed=0, offset=0, step=None):
     _chk(x, "x"); _chk(mask, "mask")
     B = x.shape[0]
     chw = x.numel() // B
@@ -377,7 +397,7 @@ def edm_noise(x, mask, P_mean, P_std, sigma_data, rnd=None, noise=None, seed=0, 
         noise = _chk(_c(noise.to(device=x.device, dtype=torch.float32)), "noise")
         assert noise.numel() == x.numel()
     _lib.call("i2r_edm_noise", _p(x), _p(mask), _p(rnd), _p(noise), _p(xn), _p(sigma), _p(weight), B, chw,
-              float(P_mean), float(P_std), float(sigma_data), int(seed), int(offset), _stream())
+              float(P_mean), float(P_std), float(sigma_data), int(seed), int(offset), _p(step), _stream())
     return xn, sigma, weight
 
 
@@ -481,19 +501,21 @@ class GroupNormFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad[:4])
         if ss is not None:
             ss = _c(ss)
-        y, mean, rstd = groupnorm_fwd(x, gamma, beta, groups, eps, ss, act, need_bwd, drop_p, seed, offset)
+        step = rng_step() if drop_p > 0.0 else None
+        y, mean, rstd = groupnorm_fwd(x, gamma, beta, groups, eps, ss, act, need_bwd, drop_p, seed, offset, step)
         if need_bwd:
             ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
-            ctx.cfg = (groups, act, drop_p, seed, offset)
+            ctx.cfg = (groups, act, drop_p, seed, offset, step)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, ss, mean, rstd = ctx.saved_tensors
-        groups, act, drop_p, seed, offset = ctx.cfg
+        groups, act, drop_p, seed, offset, step = ctx.cfg
         if ss is not None and ss.shape[0] != x.shape[0]:
             raise _lib.I2RError("groupnorm backward needs per-sample scale/shift (sigma given per sample)")
-        dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset)
+        dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset,
+                                        step)
         return dx, dg, db, dss, None, None, None, None, None, None
 
 
@@ -531,8 +553,8 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         if pre is not None:
             dy = silu_bwd(pre, dy)
-        dx, dw = linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        db = reduce_rows(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dx, dw, db = linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 

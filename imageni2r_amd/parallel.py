@@ -65,6 +65,7 @@ class GradBucketReducer:
         self._need: List[int] = []
         self._arrived: List[int] = []
         self._work: List[Optional[object]] = []
+        self.defer = False       # True: hooks only adopt/count; collectives start at launch_all() (graph-replayed backward)
         cur: List[torch.nn.Parameter] = []
         cur_bytes = 0
 
@@ -72,12 +73,13 @@ class GradBucketReducer:
             nonlocal cur, cur_bytes
             if not cur:
                 return
-            n = sum(p.numel() for p in cur)
+            pad4 = lambda k: (k + 3) // 4 * 4  # keep every view 16-byte aligned (vector loads in the optimiser kernel)
+            n = sum(pad4(p.numel()) for p in cur)
             flat = torch.zeros(n, dtype=cur[0].dtype, device=cur[0].device)
             off = 0
             for p in cur:
                 self._slot[p] = (len(self.buckets), off)
-                off += p.numel()
+                off += pad4(p.numel())
             self.buckets.append(flat)
             self._need.append(len(cur))
             self._arrived.append(0)
@@ -104,8 +106,16 @@ class GradBucketReducer:
             view.copy_(p.grad)      # first step / after zero_grad(set_to_none=True): adopt the bucket storage
             p.grad = view
         self._arrived[b] += 1
-        if self._arrived[b] == self._need[b] and self.world > 1:
+        if self._arrived[b] == self._need[b] and self.world > 1 and not self.defer:
             self._work[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def launch_all(self):
+        """Start every bucket's all-reduce now (used when backward ran inside a replayed HIP graph, where the hooks
+        do not fire)."""
+        if self.world > 1:
+            for b, flat in enumerate(self.buckets):
+                if self._work[b] is None:
+                    self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for every bucket and turn sums into means.  Buckets whose parameters got no gradient this step are

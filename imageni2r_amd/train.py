@@ -1,0 +1,118 @@
+"""GraphedTrainStep -- the diffusion train step of run_irregular.py:215-230 as ONE replayed HIP graph.
+
+    x_img, mask = model.ts_to_img_with_mask(x_ts)          # :215-216
+    x_tilde_img = model.ts_to_img(x_recon)                 # :219   (TST output; stays on PyTorch-ROCm, outside)
+    loss = step(x_tilde_img, mask)                         # :220-230 = forward_irregular + masked loss + backward
+                                                           #            + clip + AdamW + EMA
+
+Everything between the two inputs and the updated weights is captured once (torch.cuda.graph drives the stream capture;
+the library never allocates or synchronises) and replayed: ~2.5k kernel launches per step cost one graph launch on the
+host.  What makes that legal: the per-step random streams (sigma / noise draws, dropout masks) read a device-resident
+step counter that the graph itself increments, the conv weight packing is part of the graph (replays always read the
+live weights), and the optimiser tail is `FusedAdamW` whose step count / bias corrections / EMA decay live on the device.
+The only thing left out is the reference's per-step ``loss.item()`` host sync (our.py:67): the loss comes back as a
+device scalar; call ``.item()`` when you log.
+
+Data parallel: with a `GradBucketReducer` the capture is split after backward -- graph 1 (forward + backward), the
+bucketed RCCL all-reduce launched eagerly, graph 2 (optimiser tail) -- no collective is captured.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from .optim import FusedAdamW
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer: FusedAdamW, reducer=None, use_graph=True):
+        if not isinstance(optimizer, FusedAdamW):
+            raise TypeError("GraphedTrainStep needs a FusedAdamW optimiser (device-resident step state)")
+        self.model = model
+        self.opt = optimizer
+        self.reducer = reducer
+        self.use_graph = use_graph
+        self._entry = None
+        dev = next(model.net.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.I2RError("GraphedTrainStep: the model must live on a HIP ('cuda') device; no CPU fallback")
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, x_tilde_img, mask):
+        m = self.model
+        ops.counter_add(self.rng_counter, 1)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.opt.zero_grad()
+        output, weight = m.forward_irregular(x_tilde_img, mask)
+        loss = ops.MaskedLossFn.apply(output, x_tilde_img, mask, weight.reshape(-1).contiguous())
+        loss.backward()
+        return loss.detach()
+
+    def _eager(self, x_tilde_img, mask):
+        prev = ops.rng_step()
+        ops.set_rng_step(self.rng_counter)
+        try:
+            loss = self._fwd_bwd(x_tilde_img, mask)
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.opt.step()
+        finally:
+            ops.set_rng_step(prev)
+        return loss
+
+    def _capture(self, x_tilde_img, mask):
+        self.opt.prepare()
+        static_x = x_tilde_img.clone()
+        static_m = mask.clone()
+        side = torch.cuda.Stream(device=static_x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # real warm-up steps: allocator, lazy state, autograd graph shape
+            for _ in range(2):
+                self._eager(static_x, static_m)
+        torch.cuda.current_stream().wait_stream(side)
+        prev = ops.rng_step()
+        ops.set_rng_step(self.rng_counter)
+        if self.reducer is not None:
+            self.reducer.defer = True  # no collective inside the capture; launch_all() after each replay
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                ops.new_pack_epoch()  # weights are packed inside the graph: replays read the live weights
+                loss = self._fwd_bwd(static_x, static_m)
+                if self.reducer is None:
+                    self.opt.step()
+            g2 = None
+            if self.reducer is not None:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self.opt.step()
+            ops.new_pack_epoch()
+        finally:
+            ops.set_rng_step(prev)
+            if self.reducer is not None:
+                self.reducer.defer = False
+                self.reducer.finish()  # reset the arrival counters the capture-time hooks advanced
+        self._entry = (g1, g2, static_x, static_m, loss)
+
+    def __call__(self, x_tilde_img, mask):
+        """One full train step; returns the loss as a 0-dim device tensor (valid until the next call)."""
+        x_tilde_img = x_tilde_img.detach().to(torch.float32).contiguous()
+        mask = mask.to(device=x_tilde_img.device, dtype=torch.float32).contiguous()
+        if not self.model.training:
+            raise RuntimeError("GraphedTrainStep: call model.train() first (dropout is part of the captured step)")
+        if not self.use_graph:
+            return self._eager(x_tilde_img, mask)
+        if self._entry is None or tuple(self._entry[2].shape) != tuple(x_tilde_img.shape):
+            self._capture(x_tilde_img, mask)
+        g1, g2, static_x, static_m, loss = self._entry
+        static_x.copy_(x_tilde_img)
+        static_m.copy_(mask)
+        g1.replay()
+        if g2 is not None:
+            self.reducer.launch_all()
+            self.reducer.finish()
+            g2.replay()
+        return loss

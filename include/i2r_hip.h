@@ -82,16 +82,18 @@ int i2r_split_channels_f32(const float* in, float* a, float* c, int B, long n1, 
 
 /* ---- GroupNorm family: models/networks.py:104-106 fused with its consumers (:168, :173, :177, :182, :460) ---------- */
 /* y = dropout_p( act( gn(x; gamma, beta, G, eps) * (1 + scale) + shift ) );  ss = [scale | shift] (ss_batch, 2C) or
- * NULL; act: 0 identity, 1 SiLU; mean/rstd (B*G) optional outputs for backward; dropout mask = Philox(seed, offset). */
+ * NULL; act: 0 identity, 1 SiLU; mean/rstd (B*G) optional outputs for backward; dropout mask = Philox(seed,
+ * offset + (*rng_step << 20)); rng_step (device counter, see i2r_counter_add_u64) may be NULL. */
 int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
                           float* y, float* mean, float* rstd, int B, int C, int HW, int G, float eps, int act,
-                          float drop_p, uint64_t seed, uint64_t offset, i2r_stream_t stream);
-/* backward: dx (B,C,HW); dgamma_part, dbeta_part (B,C) per-sample partials (reduce with i2r_reduce_rows_f32);
+                          float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                          i2r_stream_t stream);
+/* backward: dx (B,C,HW); dgb_part (B,2C) per-sample [dgamma | dbeta] partials (reduce with i2r_reduce_rows_f32);
  * dss (B,2C) = [dscale | dshift] iff ss given. */
 int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
-                          const float* mean, const float* rstd, const float* dy, float* dx, float* dgamma_part,
-                          float* dbeta_part, float* dss, int B, int C, int HW, int G, int act, float drop_p,
-                          uint64_t seed, uint64_t offset, i2r_stream_t stream);
+                          const float* mean, const float* rstd, const float* dy, float* dx, float* dgb_part,
+                          float* dss, int B, int C, int HW, int G, int act, float drop_p, uint64_t seed,
+                          uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
 int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream);
 
 /* ---- attention: models/networks.py:113-126 (AttentionOp) + :182-184 ---------------------------------------------- */
@@ -107,8 +109,10 @@ int i2r_pos_embedding_f32(const float* x, float* out, int B, int num_channels, i
 /* y = act(x W^T + b); x (M,K), w (N,K); pre (M,N) optional pre-activation copy; act_silu fuses silu (:440,:447). */
 int i2r_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int K, int N,
                        int act_silu, i2r_stream_t stream);
-int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, int M, int K, int N,
-                       i2r_stream_t stream);
+/* autograd of the above: dx (M,K) = dy W, dw (N,K) = dy^T x, db (N) = column sums of dy; each output may be NULL
+ * (db needs dw). */
+int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K,
+                       int N, i2r_stream_t stream);
 int i2r_silu_bwd_f32(const float* pre, const float* dy, float* dx, long n, i2r_stream_t stream);
 int i2r_add_f32(const float* a, const float* b, float* y, long n, i2r_stream_t stream);
 
@@ -127,7 +131,11 @@ int i2r_edm_combine_bwd(const float* dD, const float* sigma, int nsig, float* dF
  * noise_in (B*chw) inject the two random draws (parity tests); when NULL they are drawn in-kernel (Philox). */
 int i2r_edm_noise(const float* x, const float* mask, const float* rnd_in, const float* noise_in, float* xn,
                   float* sigma, float* weight, int B, long chw, float P_mean, float P_std, float sigma_data,
-                  uint64_t seed, uint64_t offset, i2r_stream_t stream);
+                  uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
+/* *counter += inc on the stream: the device-resident step of the training RNG streams.  Kernels that take `rng_step`
+ * add (*rng_step << 20) to their Philox offset, so a captured HIP graph that contains this increment draws fresh
+ * dropout masks / noise on every replay.  (No counterpart in the reference, whose RNG is torch's global generator.) */
+int i2r_counter_add_u64(uint64_t* counter, uint64_t inc, i2r_stream_t stream);
 /* mask = 1 - isnan(x), x_clean = nan_to_num(x, 0): the mask=None branch of loss_fn_irregular (:60-62) */
 int i2r_nan_mask_f32(const float* x, float* x_clean, float* mask, long n, i2r_stream_t stream);
 /* loss_fn_irregular (:63-66): loss = mean(weight * (D*mask - x*mask)^2) over all B*chw elements; dD (optional) is
@@ -141,6 +149,17 @@ int i2r_heun_euler_f64(const double* x_hat, const float* D, double* d_cur, doubl
                        double t_next, i2r_stream_t stream);
 int i2r_heun_correct_f64(const double* x_hat, const double* x_next, const float* Dp, const double* d_cur,
                          double* x_out, long n, double t_hat, double t_next, i2r_stream_t stream);
+
+/* ---- fused optimiser tail: run_irregular.py:228-230 (clip_grad_norm_ -> AdamW.step -> LitEma, models/ema.py:26-47) -- */
+/* One multi-tensor step over every parameter.  table: device (T,6) int64 rows {param, grad, exp_avg, exp_avg_sq,
+ * ema_shadow|0, numel}; chunks: device (nchunks,2) int32 {tensor, chunk index} with i2r_opt_chunk_elems() elements per
+ * chunk; partials: nchunks floats; scalars: 8 floats (out: [0] total grad norm, [1] clip coefficient);
+ * step: device float (AdamW step count, incremented here); ema_num_updates: LitEma's int32 counter (incremented here)
+ * or NULL for no EMA.  max_norm <= 0 disables clipping.  All per-step state is device-resident: graph-capturable. */
+int i2r_opt_chunk_elems(void);
+int i2r_fused_adamw_ema_step(const void* table, const void* chunks, int nchunks, float* partials, float* scalars,
+                             float* step, int* ema_num_updates, float max_norm, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float ema_decay, int ema_warmup, i2r_stream_t stream);
 
 #ifdef __cplusplus
 }

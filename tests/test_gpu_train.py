@@ -1,0 +1,194 @@
+"""GPU tests (-m gpu) of the training-side additions: register-resident GroupNorm over every group geometry, the
+split-f16 inference conv on its own, the fused optimiser tail against torch's AdamW + clip_grad_norm_ + the
+reference's EMA rule, and the graph-captured train step against the same step run eagerly."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err, tiny_args
+from oracle import i2r_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from imageni2r_amd import ops as _ops
+    return _ops
+
+
+# (B, C, H): group sizes 16 .. 4096 elements, HW = 1 (generic kernel), 4, 16, 64, 256, 1024; ragged group counts
+@pytest.mark.parametrize("B,C,H", [(3, 128, 16), (2, 128, 32), (2, 256, 32), (5, 1024, 2), (3, 512, 2), (7, 256, 4),
+                                   (2, 384, 8), (3, 256, 1), (1, 768, 4), (2, 1024, 1), (9, 128, 8), (2, 12 * 4, 16)])
+def test_groupnorm_register_kernels_all_geometries(ops, B, C, H):
+    gen = torch.Generator().manual_seed(B * 100 + C + H)
+    x = torch.randn(B, C, H, H, generator=gen) * 1.7 + 0.3
+    w, b = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    ss = (torch.randn(B, 2 * C, generator=gen) * 0.5).requires_grad_(True)
+    dy = torch.randn(B, C, H, H, generator=gen)
+    G = min(32, C // 4)
+    for use_ss, act in ((True, True), (False, True), (False, False)):
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ssr = ss.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.group_norm(xr, G, wr, br, 1e-5)
+        if use_ss:
+            ref = ssr[:, C:, None, None] + ref * (ssr[:, :C, None, None] + 1)
+        if act:
+            ref = torch.nn.functional.silu(ref)
+        ref.backward(dy)
+        ssd = cu(ss.detach().numpy()) if use_ss else None
+        y, mean, rstd = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), G, 1e-5, ss=ssd, act=act,
+                                          save_stats=True)
+        assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+        dx, dw, db, dss = ops.groupnorm_bwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), ssd, mean, rstd,
+                                            cu(dy.numpy()), G, act)
+        assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
+        assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
+        assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+        if use_ss:
+            assert rel_err(dss.cpu().numpy(), ssr.grad.numpy()) < TOL
+
+
+def test_groupnorm_dropout_device_step(ops):
+    """Device-resident RNG step: same (seed, id, step) -> same mask; bumping the counter changes it; backward sees
+    the forward's mask."""
+    torch.manual_seed(5)
+    B, C, H, p = 4, 128, 16, 0.1
+    x = torch.randn(B, C, H, H)
+    xd, wd, bd = x.to(DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    y0, mean, rstd = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, save_stats=True)
+    ya, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=9, offset=3, step=ctr)
+    yb, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=9, offset=3, step=ctr)
+    assert torch.equal(ya, yb)
+    keep = ya != 0
+    dy = torch.ones_like(xd)
+    dxa, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy * keep.float() / (1 - p), 32, False)
+    dxb, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy, 32, False, drop_p=p, seed=9, offset=3, step=ctr)
+    assert rel_err(dxb.cpu().numpy(), dxa.cpu().numpy()) < 1e-5
+    ops.counter_add(ctr, 1)
+    assert int(ctr.item()) == 1
+    yc, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=9, offset=3, step=ctr)
+    assert not torch.equal(ya, yc)
+    assert abs((yc != 0).float().mean().item() - (1 - p)) < 0.01
+    assert torch.allclose(yc[yc != 0], y0[yc != 0] / (1 - p), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 128, 128, 16, 3), (2, 384, 256, 8, 3), (3, 1024, 512, 2, 3),
+                                            (2, 12, 128, 16, 3), (2, 128, 12, 16, 3), (2, 256, 768, 8, 1),
+                                            (5, 321, 128, 16, 3), (2, 128, 321, 16, 3), (3, 256, 256, 1, 3),
+                                            (2, 768, 256, 4, 1), (33, 64, 96, 4, 3), (1, 7, 128, 32, 3),
+                                            (2, 13, 40, 4, 1)])
+def test_conv_split_f16_vs_oracle(ops, B, Cin, Cout, H, k):
+    """The inference conv on the f16 matrix cores (x = hi + lo split, 3 MFMAs) holds the fp32 bar on every tile edge."""
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=gen) * 3.0
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, H, generator=gen)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + res.double()
+    wd = cu(w.numpy())
+    y = ops.conv2d_fwd_h2(cu(x.numpy()), tuple(w.shape), ops.conv2d_pack_h2(wd), cu(b.numpy()), cu(res.numpy()))
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-6
+
+
+def _ref_tail(params, grads, state, shadows, n_upd, lr, wd, max_norm, warmup, steps):
+    """torch AdamW + clip_grad_norm_ + the EMA rule of models/ema.py:26-47 on the CPU."""
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.AdamW(ps, lr=lr, weight_decay=wd)
+    sh = [s.clone() for s in shadows]
+    for t in range(steps):
+        for p, g in zip(ps, grads[t]):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        opt.step()
+        n_upd += 1
+        decay = min(np.float32(0.9999), np.float32(1 + n_upd) / np.float32(10 + n_upd))
+        omd = float(np.float32(1.0) - decay)
+        with torch.no_grad():
+            for s, p in zip(sh, ps):
+                if n_upd > warmup:
+                    s.sub_(omd * (s - p))
+                else:
+                    s.copy_(p)
+    return [p.detach() for p in ps], sh
+
+
+def test_fused_adamw_clip_ema_vs_torch():
+    from imageni2r_amd import FusedAdamW, TS2img_Karras
+    torch.manual_seed(0)
+    args = tiny_args(device=DEV, ema_warmup=2)
+    m = TS2img_Karras(args, DEV)
+    O.perturb_zero_init(m.net.state_dict(), seed=1234)
+    m = m.to(DEV)
+    names = [k for k, _ in m.net.named_parameters()]
+    params0 = [p.detach().cpu().clone() for p in m.net.parameters()]
+    shadows0 = [dict(m.model_ema.named_buffers())[m.model_ema.m_name2s_name[k]].detach().cpu().clone() for k in names]
+    gen = torch.Generator().manual_seed(3)
+    steps = 5
+    # gradients large enough that the clip is active on some steps and inactive on others
+    grads = [[torch.randn(p.shape, generator=gen) * (0.02 if t % 2 else 1e-4) for p in params0] for t in range(steps)]
+    opt = FusedAdamW(m.net.parameters(), lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    for t in range(steps):
+        opt.zero_grad()
+        for p, g in zip(m.net.parameters(), grads[t]):
+            if p.grad is None:
+                p.grad = g.to(DEV)
+            else:
+                p.grad.copy_(g)
+        opt.step()
+        m.on_train_batch_end()  # must be a no-op now
+        ref_norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads[t])).item()
+        assert abs(opt.grad_norm().item() - ref_norm) <= 1e-5 * ref_norm
+    ref_p, ref_s = _ref_tail(params0, grads, None, shadows0, 0, 1e-3, 1e-2, 1.0, 2, steps)
+    assert int(m.model_ema.num_updates.item()) == steps
+    bufs = dict(m.model_ema.named_buffers())
+    for k, p, rp, rs in zip(names, m.net.parameters(), ref_p, ref_s):
+        assert rel_err(p.detach().cpu().numpy(), rp.numpy()) < 2e-6, k
+        assert rel_err(bufs[m.model_ema.m_name2s_name[k]].cpu().numpy(), rs.numpy()) < 2e-6, k
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == steps
+
+
+def test_graphed_train_step_matches_eager():
+    """Same seeds, same device RNG counter: the replayed graph and the eager sequence of the same kernels give the
+    same losses and weights (up to the fp32 atomics of split wgrad), and dropout/noise really change per replay."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep, TS2img_Karras
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        m = TS2img_Karras(tiny_args(device=DEV), DEV)
+        O.perturb_zero_init(m.net.state_dict(), seed=1234)
+        m = m.to(DEV).train()
+        opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+        step = GraphedTrainStep(m, opt, use_graph=use_graph)
+        gen = torch.Generator().manual_seed(11)
+        losses = []
+        for it in range(6):
+            ts = torch.rand(4, 24, 3, generator=gen)
+            ts[0, [2, 3], :] = float("nan")
+            _, mask = m.ts_to_img_with_mask(ts.to(DEV))
+            x_tilde = m.ts_to_img(torch.rand(4, 24, 3, generator=gen).to(DEV))
+            if it == 0 and not use_graph:  # the graph path spends two real warm-up steps on its first batch
+                step(x_tilde, mask)
+                step(x_tilde, mask)
+            losses.append(step(x_tilde, mask).item())
+        assert all(np.isfinite(losses))
+        runs.append((losses, [p.detach().cpu().clone() for p in m.net.parameters()], int(step.rng_counter.item()),
+                     int(m.model_ema.num_updates.item())))
+    (le, pe, ce, ne), (lg, pg, cg, ng) = runs
+    assert ce == cg == 8 and ne == ng == 8  # stream capture records, it does not execute: counters match eager
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    for a, b in zip(pe, pg):  # Adam's sign-like first steps amplify the last-bit noise of the atomics in wgrad
+        assert rel_err(b.numpy(), a.numpy()) < 5e-3
+    assert len(set(np.round(lg, 6))) > 1  # noise / sigma draws differ between replays
