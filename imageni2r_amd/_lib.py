@@ -24,6 +24,8 @@ SIGNATURES = {
     "i2r_img_to_ts_f64": [P, P, I, I, I, I, I, I, I, P],
     "i2r_conv2d_packed_floats": [I, I, I, I],
     "i2r_conv2d_pack_weight_f32": [P, P, I, I, I, I, P],
+    "i2r_conv2d_pack_block_floats": [],
+    "i2r_conv2d_pack_multi_f32": [P, P, I, P],
     "i2r_conv2d_splitk_floats": [I, I, I, I, I, I],
     "i2r_conv2d_fwd_packed_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
     "i2r_conv2d_fwd_f32": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
@@ -32,7 +34,7 @@ SIGNATURES = {
     "i2r_conv2d_pack_weight_h2": [P, P, I, I, I, P],
     "i2r_conv2d_splitk_h2_floats": [I, I, I, I, I, I],
     "i2r_conv2d_fwd_h2": [P, P, P, P, P, P, L, I, I, I, I, I, I, P],
-    "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, P],
+    "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
     "i2r_up2_f32": [P, P, L, I, I, F, P],
     "i2r_concat_channels_f32": [P, P, P, I, L, L, P],
@@ -40,6 +42,7 @@ SIGNATURES = {
     "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P, P],
     "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
     "i2r_reduce_rows_f32": [P, P, I, I, P],
+    "i2r_reduce_rows2_f32": [P, P, P, I, I, I, P],
     "i2r_attention_fwd_f32": [P, P, P, I, I, I, P],
     "i2r_attention_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
     "i2r_pos_embedding_f32": [P, P, I, I, I, P],

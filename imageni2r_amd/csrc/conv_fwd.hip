@@ -228,6 +228,33 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// Multi-tensor form: every conv weight of the network (forward and data-gradient layouts) in ONE launch.
+// table rows {w, wp, Cout, Cin, ksize, dgrad} (int64); blockmap {tensor, block} with PACK_BLOCK packed floats per block.
+#define PACK_BLOCK 4096
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __restrict__ table,
+                                                                const int2* __restrict__ blockmap) {
+  const int2 bm = blockmap[blockIdx.x];
+  const long* e = table + 6L * bm.x;
+  const float* w = (const float*)e[0];
+  float* wp = (float*)e[1];
+  const int Cout = (int)e[2], Cin = (int)e[3], ks = (int)e[4], dgrad = (int)e[5];
+  const int M = dgrad ? Cin : Cout, C = dgrad ? Cout : Cin;
+  const int KK = ks * ks, K = C * KK, bkc = ks == 3 ? 18 : 16;
+  const int Kpad = (K + bkc - 1) / bkc * bkc, M4 = (M + 3) / 4 * 4;
+  const long total = (long)Kpad * M4;
+  const long begin = (long)bm.y * PACK_BLOCK;
+  for (long i = begin + threadIdx.x; i < begin + PACK_BLOCK && i < total; i += 256) {
+    int m = (int)(i % M4);
+    int k = (int)(i / M4);
+    float v = 0.0f;
+    if (m < M && k < K) {
+      int c = k / KK, tap = k - c * KK;
+      v = dgrad ? w[((long)c * Cin + m) * KK + (KK - 1 - tap)] : w[((long)m * Cin + c) * KK + tap];
+    }
+    wp[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline int conv_bkc(int ks) { return ks == 3 ? 18 : 16; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -248,6 +275,15 @@ extern "C" int i2r_conv2d_pack_weight_f32(const float* w, float* wp, int Cout, i
   hipLaunchKernelGGL(pack_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KK, dgrad, M,
                      M4, K, Kpad);
   return i2r_check_launch("pack_weight");
+}
+
+extern "C" int i2r_conv2d_pack_block_floats(void) { return PACK_BLOCK; }
+
+extern "C" int i2r_conv2d_pack_multi_f32(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream) {
+  I2R_REQUIRE(table && blockmap && nblocks > 0, "pack_multi: bad argument");
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table,
+                     (const int2*)blockmap);
+  return i2r_check_launch("pack_multi");
 }
 
 struct ConvPlan {

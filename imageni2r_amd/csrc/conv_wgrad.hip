@@ -1,7 +1,8 @@
 // Weight gradient of the 3x3 / 1x1 convolutions (autograd of torch.nn.functional.conv2d, models/networks.py:87) on
 // the fp32 MFMA:   dW[co][j] = sum_n dY[co][n] * Im2col[j][n],  j = (ci, r, s) in OIHW order, n = (b, y, x).
 // The reduction runs over positions; it is split over blockIdx.z (fp32 atomics into a zeroed dW) when a single pass
-// would leave CUs idle.  Bias gradient: one wave per channel.
+// would leave CUs idle.  The bias gradient (row sums of dY) falls out of the dY tiles the first column of workgroups
+// stages anyway.  `accumulate` adds into dW/db instead of overwriting them (the caller's pre-zeroed gradient buffer).
 #include "conv_common.h"
 #include "../../include/i2r_hip.h"
 
@@ -11,10 +12,12 @@
 struct WgradParams {
   const float* x;   // forward input (B, Cin, H, W)
   const float* dy;  // output gradient (B, Cout, H, W)
-  float* dw;        // (Cout, Cin*KS*KS); zero-filled by the caller when nsplit > 1
+  float* dw;        // (Cout, Cin*KS*KS); zero-filled (or holding a partial sum) when `atomic`
+  float* db;        // (Cout) bias gradient = row sums of dY, produced by the blockIdx.x == 0 column of blocks; or null
   int B, Cin, H, W, Cout, HW, K;
   long Npos;
   int chunks_per_split, nsplit;
+  int atomic;       // 1: add into dw/db with fp32 atomics (split reduction, or accumulate into existing values)
 };
 
 template <int WM, int WN, int TM, int TN, int KS>
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   float ra[EA], rb[EB];
+  float bsum[EA];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) bsum[e] = 0.0f;
+  const bool want_bias = p.db != nullptr && blockIdx.x == 0;
   auto load_chunk = [&](long nbase) {
     long n = nbase + kk;
     bool nv = n < p.Npos;
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     for (int e = 0; e < EA; ++e) {
       int co = m0 + i0 + 16 * e;
       ra[e] = (nv && co < p.Cout) ? dyb[(long)co * p.HW] : 0.0f;
+      bsum[e] += ra[e];
     }
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (co < p.Cout) {
           float* dst = p.dw + (long)co * p.K + j;
-          if (p.nsplit > 1)
+          if (p.atomic)
             atomicAdd(dst, acc[tm][tn][r]);
           else
             *dst = acc[tm][tn][r];
@@ -126,21 +134,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       }
     }
   }
-}
-
-// db[co] = sum_{b,pos} dy[b][co][pos]: one wave per channel
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
-                                                        int C, int HW) {
-  int lane = threadIdx.x & 63;
-  int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  float acc = 0.0f;
-  for (int b = 0; b < B; ++b) {
-    const float* p = dy + ((long)b * C + c) * HW;
-    for (int i = lane; i < HW; i += 64) acc += p[i];
+  if (want_bias) {  // the 16 threads that share i0 hold the 16 position phases of one output channel
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      float v = bsum[e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      int co = m0 + i0 + 16 * e;
+      if (kk == 0 && co < p.Cout) {
+        if (p.atomic)
+          atomicAdd(p.db + co, v);
+        else
+          p.db[co] = v;
+      }
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) db[c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -154,7 +162,11 @@ static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
   if (want < 1) want = 1;
   p.chunks_per_split = (int)((total_chunks + want - 1) / want);
   p.nsplit = (int)((total_chunks + p.chunks_per_split - 1) / p.chunks_per_split);
-  if (p.nsplit > 1) (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
+  if (p.nsplit > 1 && !p.atomic) {  // split reduction into fresh outputs: zero them, then add atomically
+    (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
+    if (p.db) (void)hipMemsetAsync(p.db, 0, sizeof(float) * (size_t)p.Cout, s);
+    p.atomic = 1;
+  }
   dim3 grid(i2r_cdiv(p.K, BN), i2r_cdiv(p.Cout, BM), p.nsplit);
   if (ks == 3)
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 3>), grid, dim3(256), 0, s, p);
@@ -163,11 +175,12 @@ static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
 }
 
 extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H,
-                                    int W, int Cout, int ksize, i2r_stream_t stream) {
+                                    int W, int Cout, int ksize, int accumulate, i2r_stream_t stream) {
   I2R_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
   I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size %d unsupported (1 or 3)", ksize);
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_wgrad: non-positive dimension");
-  WgradParams p{x, dy, dw, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1};
+  WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1,
+                accumulate ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;
   if (Cout <= 32)
     launch_wgrad<1, 4, 1, 1>(p, ksize, s);
@@ -177,7 +190,5 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
     launch_wgrad<2, 2, 2, 2>(p, ksize, s);
   else
     launch_wgrad<2, 2, 1, 1>(p, ksize, s);
-  if (dbias)
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(i2r_cdiv(Cout, 4)), dim3(256), 0, s, dy, dbias, B, Cout, H * W);
   return i2r_check_launch("conv2d_wgrad");
 }

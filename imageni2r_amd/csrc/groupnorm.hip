@@ -341,6 +341,18 @@ __global__ void reduce_rows_kernel(const float* __restrict__ in, float* __restri
   out[c] = acc;
 }
 
+// same, columns [0, cols_a) -> out_a and [cols_a, cols_a + cols_b) -> out_b (dgamma | dbeta into their own buffers)
+__global__ void reduce_rows2_kernel(const float* __restrict__ in, float* __restrict__ out_a, float* __restrict__ out_b,
+                                    int rows, int cols_a, int cols_b) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int cols = cols_a + cols_b;
+  if (c >= cols) return;
+  float acc = 0.0f;
+  for (int r = 0; r < rows; ++r) acc += in[(long)r * cols + c];
+  if (c < cols_a) out_a[c] = acc;
+  else out_b[c - cols_a] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int pow2_shift(int v) {
   int s = 0;
@@ -422,4 +434,12 @@ extern "C" int i2r_reduce_rows_f32(const float* in, float* out, int rows, int co
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(i2r_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, in, out, rows,
                      cols);
   return i2r_check_launch("reduce_rows");
+}
+
+extern "C" int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, int cols_a, int cols_b,
+                                    i2r_stream_t stream) {
+  I2R_REQUIRE(in && out_a && out_b && rows > 0 && cols_a > 0 && cols_b > 0, "reduce_rows2: bad argument");
+  hipLaunchKernelGGL(reduce_rows2_kernel, dim3(i2r_cdiv(cols_a + cols_b, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out_a, out_b, rows, cols_a, cols_b);
+  return i2r_check_launch("reduce_rows2");
 }

@@ -92,6 +92,14 @@ class Conv2d(torch.nn.Module):
             self._wph_key = key
         return self._wph
 
+    def packed_weight_dgrad(self):
+        """Transposed + flipped packed copy for the data gradient, only when a current one exists (made by
+        DhariwalUNet.pack_all_weights); otherwise None and backward packs on the fly."""
+        w = self.weight
+        if getattr(self, "_wpd_key", None) == (w.data_ptr(), w._version, ops.pack_epoch()):
+            return self._wpd
+        return None
+
     def forward(self, x, residual=None):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue."""
         if self.up:
@@ -102,7 +110,8 @@ class Conv2d(torch.nn.Module):
             if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
                                          None if residual is None else ops._c(residual))
-            return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight())
+            return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
+                                      self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
             raise ValueError("residual needs a convolution to fuse into")
         return x
@@ -250,6 +259,43 @@ class DhariwalUNet(torch.nn.Module):
         # dropout stream ids depend only on the position inside this network (same model => same masks per step)
         for i, mod in enumerate(m for m in self.modules() if isinstance(m, GroupNorm)):
             mod._rng_id = i + 1
+
+    def pack_all_weights(self, dgrad=True):
+        """Pack every conv weight (forward layout, and the data-gradient layout when ``dgrad``) in ONE launch into
+        persistent buffers and mark them current, so the following forward/backward launches no per-layer pack
+        kernels.  Call once per optimiser step (GraphedTrainStep does, inside its graph)."""
+        convs = [m for m in self.modules() if isinstance(m, Conv2d) and m.weight is not None]
+        key = (tuple(c.weight.data_ptr() for c in convs), bool(dgrad))
+        ps = getattr(self, "_packset", None)
+        if ps is None or ps[0] != key:
+            dev = convs[0].weight.device
+            blk = ops._lib.query("i2r_conv2d_pack_block_floats")
+            jobs = []
+            for c in convs:
+                Cout, Cin, k, _ = c.weight.shape
+                for dg in ((0, 1) if dgrad else (0,)):
+                    jobs.append((c, dg, ops._lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, dg)))
+            pool = torch.empty(sum((n + 3) // 4 * 4 for _, _, n in jobs), dtype=torch.float32, device=dev)
+            rows, bmap, views, off = [], [], [], 0
+            for t, (c, dg, n) in enumerate(jobs):
+                v = pool[off: off + n]
+                off += (n + 3) // 4 * 4
+                Cout, Cin, k, _ = c.weight.shape
+                rows.append([c.weight.data_ptr(), v.data_ptr(), Cout, Cin, k, dg])
+                bmap.extend([t, b] for b in range((n + blk - 1) // blk))
+                views.append(v)
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
+            ps = (key, jobs, views, table, bmap_t, len(bmap), pool)
+            self._packset = ps
+        _, jobs, views, table, bmap_t, nblocks, _ = ps
+        ops.pack_multi(table, bmap_t, nblocks)
+        for (c, dg, _), v in zip(jobs, views):
+            k3 = (c.weight.data_ptr(), c.weight._version, ops.pack_epoch())
+            if dg:
+                c._wpd, c._wpd_key = v, k3
+            else:
+                c._wp, c._wp_key = v, k3
 
     def embed(self, noise_labels):
         """Noise-level embedding (:437-447): posemb -> Linear+SiLU -> Linear+SiLU."""

@@ -76,6 +76,27 @@ def counter_add(counter, inc=1):
     _lib.call("i2r_counter_add_u64", _p(counter), int(inc), _stream())
 
 
+_SLOTS_ZEROED = [False]
+
+
+def slots_zeroed() -> bool:
+    return _SLOTS_ZEROED[0]
+
+
+def set_slots_zeroed(flag: bool) -> None:
+    """Promise that every parameter's ``_grad_slot`` buffer was zero-filled at the start of this step: weight-gradient
+    kernels then ADD into the slots (no per-layer memsets) instead of overwriting them."""
+    _SLOTS_ZEROED[0] = bool(flag)
+
+
+def grad_slot(param):
+    """A fresh alias of the parameter's preassigned gradient buffer (FusedAdamW / GradBucketReducer own it), or None.
+    Backward kernels write the gradient there and autograd adopts the alias as ``param.grad`` without a copy, so
+    gradient addresses never change and nothing is accumulated by separate add kernels."""
+    slot = getattr(param, "_grad_slot", None)
+    return None if slot is None else slot.detach()
+
+
 def pack_epoch() -> int:
     return _PACK_EPOCH[0]
 
@@ -128,6 +149,10 @@ def conv2d_pack(w, dgrad=False):
     wp = torch.empty((n,), dtype=torch.float32, device=w.device)
     _lib.call("i2r_conv2d_pack_weight_f32", _p(w), _p(wp), Cout, Cin, k, int(dgrad), _stream())
     return wp
+
+
+def pack_multi(table, blockmap, nblocks):
+    _lib.call("i2r_conv2d_pack_multi_f32", _p(table), _p(blockmap), int(nblocks), _stream())
 
 
 def _conv_packed(x, wp, bias, residual, Cout, k):
@@ -186,21 +211,29 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None):
     return out
 
 
-def conv2d_dgrad(dy, w):
+def conv2d_dgrad(dy, w, wpd=None):
     _chk(dy, "dy"); _chk(w, "w")
     Cout, Cin, k, _ = w.shape
     assert dy.shape[1] == Cout
-    return _conv_packed(dy, conv2d_pack(w, dgrad=True), None, None, Cin, k)
+    return _conv_packed(dy, wpd if wpd is not None else conv2d_pack(w, dgrad=True), None, None, Cin, k)
 
 
-def conv2d_wgrad(x, dy, ksize, want_bias=True):
+def conv2d_wgrad(x, dy, ksize, want_bias=True, dw=None, db=None, accumulate=False):
+    """dw / db: optional preallocated outputs (gradient slots); accumulate: add into them (they were zeroed)."""
     _chk(x, "x"); _chk(dy, "dy")
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    _lib.call("i2r_conv2d_wgrad_f32", _p(x), _p(dy), _p(dw), _p(db), B, Cin, H, W, Cout, ksize, _stream())
-    return dw, db
+    if dw is None:
+        dw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if want_bias and db is None:
+        if accumulate:
+            db = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
+        else:
+            db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_conv2d_wgrad_f32", _p(x), _p(dy), _p(dw), _p(db) if want_bias else None, B, Cin, H, W, Cout,
+              ksize, int(bool(accumulate)), _stream())
+    return dw, (db if want_bias else None)
 
 
 def down2(x, scale=0.25):
@@ -258,7 +291,8 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=Fa
     return y, mean, rstd
 
 
-def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0, step=None):
+def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0, step=None,
+                  dgamma=None, dbeta=None):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     _chk(dy, "dy")
@@ -268,6 +302,9 @@ def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, s
     _lib.call("i2r_groupnorm_bwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0], _p(mean),
               _p(rstd), _p(dy), _p(dx), _p(part), _p(dss), B, C, HW, groups, int(bool(act)),
               float(drop_p), int(seed), int(offset), _p(step), _stream())
+    if dgamma is not None and dbeta is not None:  # straight into the parameters' gradient slots
+        _lib.call("i2r_reduce_rows2_f32", _p(part), _p(dgamma), _p(dbeta), B, C, C, _stream())
+        return dx, dgamma, dbeta, dss
     dgb = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
     _lib.call("i2r_reduce_rows_f32", _p(part), _p(dgb), B, 2 * C, _stream())
     return dx, dgb[:C], dgb[C:], dss
@@ -315,12 +352,14 @@ def linear_fwd(x, w, bias=None, act=False, save_pre=False):
     return y, pre
 
 
-def linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=False):
+def linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=False, dw=None, db=None):
     M, K = x.shape
     N = w.shape[0]
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty_like(w) if (need_dw or need_db) else None
-    db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    if dw is None:
+        dw = torch.empty_like(w) if (need_dw or need_db) else None
+    if db is None:
+        db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
     _lib.call("i2r_linear_bwd_f32", _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), M, K, N, _stream())
     return dx, dw, db
 
@@ -442,10 +481,12 @@ class Conv2dFn(torch.autograd.Function):
     """conv2d + bias + residual (networks.py:87-89 and the x.add_ of :178/:185)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, wp=None):
+    def forward(ctx, x, w, bias, residual, wp=None, wpd=None):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.wpd = wpd  # weights already packed for the data gradient (DhariwalUNet.pack_all_weights), or None
+        ctx.slots = (getattr(w, "_grad_slot", None), getattr(bias, "_grad_slot", None))
         return conv2d_fwd(x, w, bias, None if residual is None else _c(residual), wp)
 
     @staticmethod
@@ -454,11 +495,15 @@ class Conv2dFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad(dy, w)
+            dx = conv2d_dgrad(dy, w, ctx.wpd)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv2d_wgrad(x, dy, w.shape[-1], want_bias=ctx.has_bias)
+            sw, sb = ctx.slots
+            use = sw is not None and (sb is not None or not ctx.has_bias)
+            dw, db = conv2d_wgrad(x, dy, w.shape[-1], want_bias=ctx.has_bias, dw=sw.detach() if use else None,
+                                  db=sb.detach() if (use and ctx.has_bias) else None,
+                                  accumulate=use and slots_zeroed())
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
 class Down2Fn(torch.autograd.Function):
@@ -506,6 +551,7 @@ class GroupNormFn(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
             ctx.cfg = (groups, act, drop_p, seed, offset, step)
+            ctx.slots = (getattr(gamma, "_grad_slot", None), getattr(beta, "_grad_slot", None))
         return y
 
     @staticmethod
@@ -514,8 +560,10 @@ class GroupNormFn(torch.autograd.Function):
         groups, act, drop_p, seed, offset, step = ctx.cfg
         if ss is not None and ss.shape[0] != x.shape[0]:
             raise _lib.I2RError("groupnorm backward needs per-sample scale/shift (sigma given per sample)")
+        sg, sb = ctx.slots
+        use = sg is not None and sb is not None
         dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset,
-                                        step)
+                                        step, sg.detach() if use else None, sb.detach() if use else None)
         return dx, dg, db, dss, None, None, None, None, None, None
 
 
@@ -545,6 +593,7 @@ class LinearFn(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, w, pre)
             ctx.has_bias = bias is not None
+            ctx.slots = (getattr(w, "_grad_slot", None), getattr(bias, "_grad_slot", None))
         return y
 
     @staticmethod
@@ -553,8 +602,10 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         if pre is not None:
             dy = silu_bwd(pre, dy)
+        sw, sb = ctx.slots
         dx, dw, db = linear_bwd(x, w, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                ctx.has_bias and ctx.needs_input_grad[2])
+                                ctx.has_bias and ctx.needs_input_grad[2],
+                                dw=None if sw is None else sw.detach(), db=None if sb is None else sb.detach())
         return dx, dw, db, None
 
 

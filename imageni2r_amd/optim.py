@@ -60,28 +60,40 @@ class FusedAdamW(torch.optim.Optimizer):
         return step
 
     def bind_grads(self):
-        """Give every parameter without a gradient a view of one flat, zero-filled buffer (stable addresses)."""
+        """Give every parameter that has neither a gradient nor a gradient slot a slot in one flat buffer.  A slot
+        (``p._grad_slot``) is where the backward kernels write that parameter's gradient (ops.grad_slot); autograd
+        then adopts it as ``p.grad`` without a copy, so gradient addresses are the same on every step."""
         ps = self._params()
-        missing = [p for p in ps if p.grad is None]
+        missing = [p for p in ps if p.grad is None and getattr(p, "_grad_slot", None) is None]
         if missing:
             n = sum((p.numel() + 3) // 4 * 4 for p in missing)
             flat = torch.zeros(n, dtype=torch.float32, device=missing[0].device)
             off = 0
             for p in missing:
-                p.grad = flat[off: off + p.numel()].view_as(p)
+                p._grad_slot = flat[off: off + p.numel()].view_as(p)
                 off += (p.numel() + 3) // 4 * 4
             self._flat_grad = flat if len(missing) == len(ps) else None
+        for p in ps:
+            if p.grad is None:
+                p.grad = p._grad_slot.detach()
         return ps
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Zero the gradients IN PLACE (their addresses are part of the kernel's pointer table)."""
+    def zero_grad(self, set_to_none: bool = True):
+        """Parameters with a gradient slot: drop ``.grad`` (backward re-creates it at the slot's address) and zero the
+        flat slot buffer with one memset; others: zero in place (their addresses are in the kernel's table)."""
         ps = self._params()
-        if self._flat_grad is not None and all(p.grad is not None for p in ps):
+        if self._flat_grad is not None and all(getattr(p, "_grad_slot", None) is not None for p in ps):
             self._flat_grad.zero_()
-            return
+            for p in ps:
+                p.grad = None
+            return True
+        for p in ps:
+            if getattr(p, "_grad_slot", None) is not None:
+                p.grad = None
         grads = [p.grad for p in ps if p.grad is not None]
         if grads:
             torch._foreach_zero_(grads)
+        return False
 
     def _build_table(self, ps):
         shadows = None
@@ -95,7 +107,7 @@ class FusedAdamW(torch.optim.Optimizer):
         for t, p in enumerate(ps):
             st = self.state[p]
             sh = shadows[t] if shadows is not None else None
-            rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+            rows.append([p.data_ptr(), self._gptr(p), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                          sh.data_ptr() if sh is not None else 0, p.numel()])
             chunks.extend([t, c] for c in range((p.numel() + chunk - 1) // chunk))
         dev = ps[0].device
@@ -105,15 +117,21 @@ class FusedAdamW(torch.optim.Optimizer):
         self._nchunks = len(chunks)
         self._ema_decay = float(self._ema.decay) if self._ema is not None else 0.0  # one host read, at table build
 
+    @staticmethod
+    def _gptr(p):
+        if p.grad is not None:
+            return p.grad.data_ptr()
+        return p._grad_slot.data_ptr()
+
     def _key(self, ps):
-        return tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        return tuple((p.data_ptr(), self._gptr(p)) for p in ps)
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FusedAdamW.step: closures are not supported")
         ps = self._params()
-        if any(p.grad is None for p in ps):
+        if any(p.grad is None and getattr(p, "_grad_slot", None) is None for p in ps):
             ps = self.bind_grads()
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:  # the table cannot change inside a capture; it was validated when the capture was made

@@ -93,6 +93,8 @@ class GradBucketReducer:
             cur.append(p)
             cur_bytes += p.numel() * p.element_size()
         close()
+        for p in self.params:  # backward kernels of imageni2r_amd write gradients straight into the bucket (ops.grad_slot)
+            p._grad_slot = self._view(p)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _view(self, p):
@@ -133,8 +135,14 @@ class GradBucketReducer:
         """Zero the buckets in place (keeps the views bound; cheaper than set_to_none + re-adoption)."""
         for flat in self.buckets:
             flat.zero_()
+        for p in self.params:
+            p.grad = None  # re-created at the slot's address by the next backward (no accumulate kernels)
+        return True
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            if hasattr(p, "_grad_slot"):
+                del p._grad_slot

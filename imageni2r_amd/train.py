@@ -42,13 +42,15 @@ class GraphedTrainStep:
     def _fwd_bwd(self, x_tilde_img, mask):
         m = self.model
         ops.counter_add(self.rng_counter, 1)
-        if self.reducer is not None:
-            self.reducer.zero_grad()
-        else:
-            self.opt.zero_grad()
-        output, weight = m.forward_irregular(x_tilde_img, mask)
-        loss = ops.MaskedLossFn.apply(output, x_tilde_img, mask, weight.reshape(-1).contiguous())
-        loss.backward()
+        zeroed = self.reducer.zero_grad() if self.reducer is not None else self.opt.zero_grad()
+        m.net.model.pack_all_weights(dgrad=True)  # one launch instead of two pack kernels per conv
+        ops.set_slots_zeroed(bool(zeroed))        # weight-gradient kernels add into the zeroed slots: no memsets
+        try:
+            output, weight = m.forward_irregular(x_tilde_img, mask)
+            loss = ops.MaskedLossFn.apply(output, x_tilde_img, mask, weight.reshape(-1).contiguous())
+            loss.backward()
+        finally:
+            ops.set_slots_zeroed(False)
         return loss.detach()
 
     def _eager(self, x_tilde_img, mask):

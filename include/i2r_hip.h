@@ -46,6 +46,10 @@ int i2r_img_to_ts_f64(const double* img, float* ts, int B, int L, int C, int del
 long i2r_conv2d_packed_floats(int Cout, int Cin, int ksize, int dgrad);
 int i2r_conv2d_pack_weight_f32(const float* w /* OIHW */, float* wp, int Cout, int Cin, int ksize, int dgrad,
                                i2r_stream_t stream);
+/* all conv weights of a network in one launch: table = device (T,6) int64 rows {w, wp, Cout, Cin, ksize, dgrad},
+ * blockmap = device (nblocks,2) int32 {tensor, block}, one block per i2r_conv2d_pack_block_floats() packed floats */
+int i2r_conv2d_pack_block_floats(void);
+int i2r_conv2d_pack_multi_f32(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream);
 /* floats of split-K workspace this shape wants (0 = none); passing less (or NULL) only disables split-K */
 long i2r_conv2d_splitk_floats(int B, int Cin, int H, int W, int Cout, int ksize);
 int i2r_conv2d_fwd_packed_f32(const float* x, const float* wp, const float* bias, const float* residual, float* out,
@@ -68,9 +72,10 @@ long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksi
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       i2r_stream_t stream);
-/* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) is overwritten; dbias (Cout) may be NULL. */
+/* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) and dbias (Cout, may be NULL) are overwritten, or added to when
+ * `accumulate` is set (gradient buffers zeroed once per step by the caller). */
 int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
-                         int Cout, int ksize, i2r_stream_t stream);
+                         int Cout, int ksize, int accumulate, i2r_stream_t stream);
 /* resample_filter [1,1] (:64-65, :82-85): y = scale * 2x2 box sum (down; scale 0.25 forward) and
  * y = scale * nearest x2 (up; scale 1 forward); each is the other's adjoint with the scales swapped. */
 int i2r_down2_f32(const float* x, float* y, long planes, int H, int W, float scale, i2r_stream_t stream);
@@ -95,6 +100,9 @@ int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta,
                           float* dss, int B, int C, int HW, int G, int act, float drop_p, uint64_t seed,
                           uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
 int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream);
+/* same with the columns split over two outputs: [0,cols_a) -> out_a, [cols_a, cols_a+cols_b) -> out_b */
+int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, int cols_a, int cols_b,
+                         i2r_stream_t stream);
 
 /* ---- attention: models/networks.py:113-126 (AttentionOp) + :182-184 ---------------------------------------------- */
 /* qkv (B, 3*heads*64, T) interleaved (head, d, {q,k,v}); out (B, heads*64, T); lse (B*heads*T) optional (backward). */

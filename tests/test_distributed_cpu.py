@@ -99,5 +99,9 @@ def test_reducer_single_process_is_identity():
     ref = [p.grad.clone() for p in m.parameters()]
     red.finish()
     assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
-    red.zero_grad()
-    assert all((p.grad == 0).all() for p in m.parameters())
+    red.zero_grad()  # buckets zeroed in place, .grad dropped: the next backward lands at the slot address again
+    assert all(p.grad is None for p in m.parameters())
+    assert all((b == 0).all() for b in red.buckets)
+    m(x).sum().backward()
+    assert all(p.grad.data_ptr() == p._grad_slot.data_ptr() for p in m.parameters())
+    assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
