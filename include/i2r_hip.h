@@ -47,7 +47,7 @@ long i2r_conv2d_packed_floats(int Cout, int Cin, int ksize, int dgrad);
 int i2r_conv2d_pack_weight_f32(const float* w /* OIHW */, float* wp, int Cout, int Cin, int ksize, int dgrad,
                                i2r_stream_t stream);
 /* all conv weights of a network in one launch: table = device (T,6) int64 rows {w, wp, Cout, Cin, ksize, dgrad},
- * blockmap = device (nblocks,2) int32 {tensor, block}, one block per i2r_conv2d_pack_block_floats() packed floats */
+ * blockmap = device (nblocks,2) int32 {tensor, block}, one block per pack_block_floats packed floats (query below) */
 int i2r_conv2d_pack_block_floats(void);
 int i2r_conv2d_pack_multi_f32(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream);
 /* floats of split-K workspace this shape wants (0 = none); passing less (or NULL) only disables split-K */
@@ -160,7 +160,7 @@ int i2r_heun_correct_f64(const double* x_hat, const double* x_next, const float*
 
 /* ---- fused optimiser tail: run_irregular.py:228-230 (clip_grad_norm_ -> AdamW.step -> LitEma, models/ema.py:26-47) -- */
 /* One multi-tensor step over every parameter.  table: device (T,6) int64 rows {param, grad, exp_avg, exp_avg_sq,
- * ema_shadow|0, numel}; chunks: device (nchunks,2) int32 {tensor, chunk index} with i2r_opt_chunk_elems() elements per
+ * ema_shadow|0, numel}; chunks: device (nchunks,2) int32 {tensor, chunk index} with opt_chunk_elems (query below) elements per
  * chunk; partials: nchunks floats; scalars: 8 floats (out: [0] total grad norm, [1] clip coefficient);
  * step: device float (AdamW step count, incremented here); ema_num_updates: LitEma's int32 counter (incremented here)
  * or NULL for no EMA.  max_norm <= 0 disables clipping.  All per-step state is device-resident: graph-capturable. */
