@@ -293,11 +293,15 @@ struct ConvPlan {
 
 static ConvPlan conv_plan(long Npos, int Cout, int Kpad, int ks, bool allow_split) {
   ConvPlan pl;
+  // Tile choice, from a sweep over the B1/C layer shapes at batch 32..1024 (tools/conv_sweep.py): 128x128 tiles once
+  // they alone fill the chip; below that 64x64 tiles (4x the workgroups, no slower per flop on the 64-cycle fp32 MFMA)
+  // and split-K up to ~1024 workgroups with at least 8 chunks (144 / 128 k) per split.
+  const long tiles128 = (long)i2r_cdiv(Npos, 128) * i2r_cdiv(Cout, 128);
   if (Cout <= 32) {
     pl.variant = 2; pl.bm = 32; pl.bn = 128;
   } else if (Npos <= 32) {
     pl.variant = 3; pl.bm = 128; pl.bn = 32;
-  } else if (Cout <= 64 || Npos <= 64) {
+  } else if (Cout <= 64 || Npos <= 64 || tiles128 < 256) {
     pl.variant = 1; pl.bm = 64; pl.bn = 64;
   } else {
     pl.variant = 0; pl.bm = 128; pl.bn = 128;
@@ -310,12 +314,16 @@ static ConvPlan conv_plan(long Npos, int Cout, int Kpad, int ks, bool allow_spli
   long tiles = (long)i2r_cdiv(Npos, pl.bn) * i2r_cdiv(Cout, pl.bm);
   int chunks = Kpad / conv_bkc(ks);
   int nsplit = 1;
-  if (allow_split && tiles < 256) {
-    long want = (640 + tiles - 1) / tiles;  // ~2.5 blocks per CU
-    long maxs = chunks / 6;                 // keep >= 6 chunks (>= 96 k) per split
+  if (allow_split && tiles < 512) {
+    long want = (1024 + tiles - 1) / tiles;
+    long maxs = chunks / 8;
     if (want > maxs) want = maxs;
-    if (want > 64) want = 64;
+    if (want > 32) want = 32;
     if (want > 1) nsplit = (int)want;
+  }
+  if (const char* ev = getenv("I2R_CONV_NSPLIT")) {  // tuning/debug override
+    int v = atoi(ev);
+    if (v >= 1 && allow_split) nsplit = v > chunks ? chunks : v;
   }
   pl.chunks_per_split = (chunks + nsplit - 1) / nsplit;
   pl.nsplit = (chunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
