@@ -39,6 +39,7 @@ struct ConvHParams {
   long Npos;
   int chunks_per_split, nsplit;
   long slab_stride;
+  int ablate;  // tuning only (I2R_H2_ABLATE): 1 = skip the epilogue stores, 2 = skip the main loop
 };
 
 __device__ __forceinline__ float bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -58,25 +59,54 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
   }
 }
 
+// pre-split activations: one 32-bit word per element = f16 hi | f16 lo << 16 (written by the producing kernel, e.g.
+// GroupNorm with split_out); 8 words -> the hi and lo fragments with byte permutes only.
+__device__ __forceinline__ void unpack8(const float* v, half8& hi, half8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned w0 = __builtin_bit_cast(unsigned, v[2 * i]), w1 = __builtin_bit_cast(unsigned, v[2 * i + 1]);
+    h[i] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    l[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+  }
+  uint4v hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+  hi = __builtin_bit_cast(half8, hv);
+  lo = __builtin_bit_cast(half8, lv);
+}
+
+// value of lane-1 / lane+1 (0 into the wave's first / last lane): DPP wave shifts, no LDS, no memory
+__device__ __forceinline__ float from_lane_below(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
 // KS = 3: chunk = (kernel row r, 16-channel block), KC = 48 (k = s*16 + c).   KS = 1: chunk = 64 channels, KC = 64.
-template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(ConvHParams p) {
-  constexpr int BM = 128, BN = 128;
+// Workgroup tile: 128 output channels x 32*NW positions.  The NW wavefronts split the POSITIONS (32 each) and every
+// wave covers all 128 channels: the weight tile is shared through LDS (double buffered, one barrier per chunk), while
+// each lane loads exactly the activation elements its own MFMAs consume -- straight from global memory into
+// registers, no LDS round trip, no cross-wave traffic.
+//   SPLIT: activations arrive pre-split (see unpack8).
+//   DPP (3x3, image width a power of two <= 32): only the centre tap column is loaded; the left / right taps are the
+//   neighbouring lanes' values (lane = position along the image row), fetched with DPP wave shifts and zeroed at the
+//   row ends -- a third of the vector-memory instructions and L1/L2 bytes of the plain im2col gather.
+template <int KS, bool SPLIT, int NW, bool DPP>
+__global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) {
+  constexpr int BM = 128, BN = 32 * NW, NT = 64 * NW;
   constexpr int KC = (KS == 3) ? 48 : 64;
   constexpr int NKS = KC / 16;             // MFMA k-steps per chunk
   constexpr int ROWL = KC * 2 + 16;        // LDS row bytes (odd multiple of 16 B -> conflict-free b128 rows)
   constexpr int RB = 2 * KC * 2;           // global bytes per packed weight row (hi | lo)
   constexpr int PPR = RB / 16;             // 16-B pieces per weight row
-  constexpr int NA = BM * PPR / 256;       // weight pieces per thread per chunk (6 or 8)
-  constexpr int NSEG = (KS == 3) ? 3 : 4;  // 8-channel segments a thread converts per chunk (one ds_write pair each)
+  constexpr int NA = BM * PPR / NT;        // weight pieces per thread per chunk
+  constexpr int ABUF = 2 * BM * ROWL;      // bytes of one weight stage (hi rows, then lo rows)
+  constexpr int NRAW = (KS == 3 && DPP) ? 1 : NKS;  // raw activation register sets per chunk
+  static_assert(BM * PPR % NT == 0, "weight tile must divide over the threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ah = smem;                       // [BM][ROWL]
-  unsigned char* Al = Ah + BM * ROWL;
-  unsigned char* Bh = Al + BM * ROWL;             // [BN][ROWL]
-  unsigned char* Bl = Bh + BN * ROWL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int l31 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * BM;
   const long n0 = (long)blockIdx.x * BN;
 
@@ -88,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(ConvHParams p) {
   int ldsA[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    int idx = tid + 256 * j;
+    int idx = tid + NT * j;
     int row = idx / PPR, piece = idx % PPR;
     voffA[j] = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * RB + piece * 16) : OOR;
     int lo = piece >= PPR / 2;
@@ -96,9 +126,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(ConvHParams p) {
   }
   const unsigned stepA = (unsigned)p.Cout * RB;  // bytes per chunk of packed weights
 
-  // ---- im2col descriptors: thread = (position n, channel half g)
-  const int b_j = tid & 127, g = tid >> 7;
-  const long nj = n0 + b_j;
+  // ---- im2col descriptors: lane = (position n0 + 32*wave + l31, channel half h)
+  const long nj = n0 + wave * 32 + l31;
   const bool nvalid = nj < p.Npos;
   int pb = 0, py = 0, px = 0;
   if (nvalid) {
@@ -107,137 +136,183 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(ConvHParams p) {
     py = pos / p.W;
     px = pos % p.W;
   }
+  const bool has_left = px > 0, has_right = px < p.W - 1;
   const unsigned chan_bytes = (unsigned)p.HW * 4;
   unsigned voffB[3];
-  auto set_row = [&](int r) {  // voffsets of the three tap columns of kernel row r for this thread's position
+  auto set_row = [&](int r) {  // voffsets of the tap columns of kernel row r for this lane's position
+    int iy = py + r - 1;
+    bool rok = nvalid && (unsigned)iy < (unsigned)p.H;
+    long off = ((long)pb * p.Cin + 8 * h) * p.HW + iy * p.W + px;
+    if (DPP) {
+      voffB[0] = rok ? (unsigned)(off * 4) : OOR;
+    } else {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      int iy = py + r - 1, ix = px + s - 1;
-      bool ok = nvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      long off = ((long)pb * p.Cin + 8 * g) * p.HW + iy * p.W + ix;
-      voffB[s] = ok ? (unsigned)(off * 4) : OOR;
+      for (int s = 0; s < 3; ++s) {
+        int ix = px + s - 1;
+        voffB[s] = (rok && (unsigned)ix < (unsigned)p.W) ? (unsigned)((off + s - 1) * 4) : OOR;
+      }
     }
   };
   if (KS == 1) {
-    long off = ((long)pb * p.Cin + 8 * g) * p.HW + py * p.W + px;
+    long off = ((long)pb * p.Cin + 8 * h) * p.HW + py * p.W + px;
     voffB[0] = nvalid ? (unsigned)(off * 4) : OOR;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
   uint4v ra[NA];
-  float rb[NSEG][8];
-  // chunk c -> (r, cb) for 3x3 (r-major so voffB changes only 3 times), cb for 1x1
-  auto load_chunk = [&](int c) {
-    unsigned sA = (unsigned)c * stepA;
+  float rb[NRAW][8];
+  // live = false (a chunk past this workgroup's range): the scalar offset is pushed out of the buffer, so the loads
+  // return 0 without touching memory -- keeps the main loop branch-free
+  auto load_a = [&](int c, bool live) {
+    unsigned sA = live ? (unsigned)c * stepA : OOR;
 #pragma unroll
     for (int j = 0; j < NA; ++j) ra[j] = bufload4(rA, voffA[j], sA);
+  };
+  auto store_a = [&](int buf) {
+    unsigned char* dst = smem + buf * ABUF;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(dst + ldsA[j]) = ra[j];
+  };
+  // Channels past Cin in the last channel block need no masking: their packed weights are zero, and what the load
+  // returns there is either a finite activation of the next sample or the buffer unit's out-of-range 0.
+  auto load_b = [&](int c, bool live) {
+    const unsigned dead = live ? 0u : OOR;
     if (KS == 3) {
       int cb = c % p.nCB;
-      int cvalid = p.Cin - cb * 16 - 8 * g;  // channels of this thread's half that exist (uniform per half-block)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        unsigned sB = (unsigned)(cb * 16 + j) * chan_bytes;
-        bool cok = j < cvalid;
+        unsigned sB = (unsigned)(cb * 16 + j) * chan_bytes + dead;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) rb[s][j] = bufload(rB, cok ? voffB[s] : OOR, sB);
+        for (int s = 0; s < NRAW; ++s) rb[s][j] = bufload(rB, voffB[s], sB);
       }
     } else {
-      int cvalid = p.Cin - c * 64 - 8 * g;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          unsigned sB = (unsigned)(c * 64 + q * 16 + j) * chan_bytes;
-          rb[q][j] = bufload(rB, (q * 16 + j < cvalid) ? voffB[0] : OOR, sB);
+          unsigned sB = (unsigned)(c * 64 + q * 16 + j) * chan_bytes + dead;
+          rb[q][j] = bufload(rB, voffB[0], sB);
         }
     }
   };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(Ah + ldsA[j]) = ra[j];
-#pragma unroll
-    for (int q = 0; q < NSEG; ++q) {
-      half8 hi, lo;
-      split8(rb[q], hi, lo);
-      int o = b_j * ROWL + (q * 16 + 8 * g) * 2;
-      *reinterpret_cast<half8*>(Bh + o) = hi;
-      *reinterpret_cast<half8*>(Bl + o) = lo;
-    }
+  auto to_frag = [&](const float* v, half8& hi, half8& lo) {
+    if (SPLIT) unpack8(v, hi, lo);
+    else split8(v, hi, lo);
   };
 
   const int total_chunks = (KS == 3) ? 3 * p.nCB : p.nCB;
   int c_begin = blockIdx.z * p.chunks_per_split;
   int c_end = c_begin + p.chunks_per_split;
   if (c_end > total_chunks) c_end = total_chunks;
-  if (c_begin < c_end) {
+  if (c_begin < c_end && !(p.ablate & 2)) {
     int cur_r = -1;
-    auto prep = [&](int c) {
+    auto prep_b = [&](int c) {
       if (KS == 3) {
         int r = c / p.nCB;
         if (r != cur_r) { set_row(r); cur_r = r; }
       }
-      load_chunk(c);
+      load_b(c, c < c_end);
     };
-    prep(c_begin);
-    store_chunk();
-    __syncthreads();
-    const unsigned char* a_base = Ah + ((wm * 64 + l31) * ROWL + 16 * h);
-    const unsigned char* b_base = Bh + ((wn * 64 + l31) * ROWL + 16 * h);
-    for (int c = c_begin; c < c_end; ++c) {
-      if (c + 1 < c_end) prep(c + 1);
+    // fragments of one chunk's activations out of the raw registers
+    auto build_frags = [&](half8* fh, half8* fl) {
+      if (KS == 3 && DPP) {
+        float tl[8], tr[8];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        half8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          ah[t] = *reinterpret_cast<const half8*>(a_base + t * 32 * ROWL + ks * 32);
-          al[t] = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL + ks * 32);
-          bh[t] = *reinterpret_cast<const half8*>(b_base + t * 32 * ROWL + ks * 32);
-          bl[t] = *reinterpret_cast<const half8*>(b_base + BN * ROWL + t * 32 * ROWL + ks * 32);
+        for (int j = 0; j < 8; ++j) {
+          float lft = from_lane_below(rb[0][j]), rgt = from_lane_above(rb[0][j]);
+          tl[j] = has_left ? lft : 0.0f;
+          tr[j] = has_right ? rgt : 0.0f;
         }
+        to_frag(tl, fh[0], fl[0]);
+        to_frag(rb[0], fh[1], fl[1]);
+        to_frag(tr, fh[2], fl[2]);
+      } else {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          }
+        for (int ks = 0; ks < NKS; ++ks) to_frag(rb[ks], fh[ks], fl[ks]);
       }
-      __syncthreads();            // every wave has read chunk c out of LDS
-      if (c + 1 < c_end) store_chunk();
-      __syncthreads();            // chunk c+1 visible
+    };
+    load_a(c_begin, true);
+    prep_b(c_begin);
+    store_a(0);
+    half8 bh[NKS], bl[NKS];
+    build_frags(bh, bl);
+    load_a(c_begin + 1, c_begin + 1 < c_end);
+    prep_b(c_begin + 1);
+    __syncthreads();
+    // Steady state of chunk c: weight stage c in LDS, activation fragments of c in bh/bl, and the loads of chunk c+1
+    // (weights -> ra, activations -> rb) in flight.  The fragment build for c+1 is VALU work placed beside the last
+    // k-step's MFMAs of chunk c; the loads of c+2 are issued as soon as ra / rb are free again.
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = (c - c_begin) & 1;
+      const unsigned char* a_base = smem + buf * ABUF + (l31 * ROWL + 16 * h);
+      half8 af[2][8];
+      auto load_frags = [&](int slot, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          af[slot][2 * t] = *reinterpret_cast<const half8*>(a_base + t * 32 * ROWL + ks * 32);
+          af[slot][2 * t + 1] = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL + ks * 32);
+        }
+      };
+      auto mfma12 = [&](int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bh[ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bl[ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t + 1], bh[ks], acc[t], 0, 0, 0);
+        }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS - 1; ++ks) {
+        load_frags((ks + 1) & 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // last k-step: its 12 MFMAs interleaved with the next chunk's fragment build (VALU only)
+      // Everything below is unconditional so that it stays ONE scheduling region: past the last chunk the stores hit
+      // the idle LDS stage, the fragment build chews on stale registers and the loads run off the end of the buffers
+      // (the buffer unit returns 0) -- all harmless, none of it is read.
+      half8 nh[NKS], nl[NKS];
+      store_a(buf ^ 1);  // stage c+1 (its last readers, chunk c-1, are behind the previous barrier)
+      mfma12(NKS - 1);
+      build_frags(nh, nl);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) { bh[ks] = nh[ks]; bl[ks] = nl[ks]; }
+      load_a(c + 2, c + 2 < c_end);
+      prep_b(c + 2);
+      __syncthreads();
     }
   }
 
   const bool direct = p.nsplit == 1;
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
+  if (nvalid) {
+    const int pos = (int)(nj % p.HW);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    long n = n0 + (wn * 2 + tn) * 32 + l31;
-    if (n >= p.Npos) continue;
-    int b = (int)(n / p.HW);
-    int pos = (int)(n % p.HW);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int co = m0 + (wm * 2 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        int co = m0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (co < p.Cout) {
-          long o = ((long)b * p.Cout + co) * p.HW + pos;
-          float v = acc[tm][tn][r] * WSCALE_INV;
+          long o = ((long)pb * p.Cout + co) * p.HW + pos;
+          float v = acc[t][r] * WSCALE_INV;
           if (direct) {
             if (p.bias) v += p.bias[co];
             if (p.res) v += p.res[o];
           }
-          outp[o] = v;
+          if (!(p.ablate & 1) || v == 12345.678f) outp[o] = v;
         }
       }
     }
@@ -306,8 +381,19 @@ extern "C" int i2r_conv2d_pack_weight_h2(const float* w, void* wp, int Cout, int
   return i2r_check_launch("pack_weight_h2");
 }
 
-static void h2_plan(long Npos, int Cout, int chunks, bool allow_split, int& nsplit, int& cps) {
-  long tiles = (long)i2r_cdiv(Npos, 128) * i2r_cdiv(Cout, 128);
+// positions per workgroup: 256 (8 waves, one workgroup per CU) once that still gives every CU >= 2 workgroups of work,
+// else 128 (4 waves, two workgroups per CU)
+static int h2_bn(long Npos, int Cout) {
+  if (const char* ev = getenv("I2R_H2_BN")) {  // tuning/debug override
+    int v = atoi(ev);
+    if (v == 128 || v == 256) return v;
+  }
+  return ((long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= 512) ? 256 : 128;
+}
+
+static void h2_plan(long Npos, int Cout, int chunks, bool allow_split, int& bn, int& nsplit, int& cps) {
+  bn = h2_bn(Npos, Cout);
+  long tiles = (long)i2r_cdiv(Npos, bn) * i2r_cdiv(Cout, 128);
   nsplit = 1;
   if (allow_split && tiles < 256) {
     long want = (512 + tiles - 1) / tiles;
@@ -321,15 +407,15 @@ static void h2_plan(long Npos, int Cout, int chunks, bool allow_split, int& nspl
 }
 
 extern "C" long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksize) {
-  int nsplit, cps;
+  int bn, nsplit, cps;
   long Npos = (long)B * H * W;
-  h2_plan(Npos, Cout, h2_chunks(Cin, ksize), true, nsplit, cps);
+  h2_plan(Npos, Cout, h2_chunks(Cin, ksize), true, bn, nsplit, cps);
   return nsplit > 1 ? (long)nsplit * Npos * Cout : 0;
 }
 
 extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual,
                                  float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W,
-                                 int Cout, int ksize, i2r_stream_t stream) {
+                                 int Cout, int ksize, int x_is_split, i2r_stream_t stream) {
   I2R_REQUIRE(x && wp && out, "conv2d_fwd_h2: null pointer");
   I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_fwd_h2: kernel size %d unsupported (1 or 3)", ksize);
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_fwd_h2: non-positive dimension");
@@ -339,8 +425,8 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
               "conv2d_fwd_h2: input (%ld B) or packed weights (%ld B) exceed the 2 GiB buffer-addressing limit",
               x_bytes, wp_bytes);
   long Npos = (long)B * H * W;
-  int chunks = h2_chunks(Cin, ksize), nsplit, cps;
-  h2_plan(Npos, Cout, chunks, splitk_ws != nullptr, nsplit, cps);
+  int chunks = h2_chunks(Cin, ksize), bn, nsplit, cps;
+  h2_plan(Npos, Cout, chunks, splitk_ws != nullptr, bn, nsplit, cps);
   if (nsplit > 1 && (long)nsplit * Npos * Cout > splitk_floats) { nsplit = 1; cps = chunks; }
   ConvHParams p;
   p.x = x; p.wp = wp; p.bias = bias; p.res = residual;
@@ -348,19 +434,37 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
   p.x_bytes = (unsigned)x_bytes; p.wp_bytes = (unsigned)wp_bytes;
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.HW = H * W; p.nCB = h2_ncb(Cin, ksize);
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
+  { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(i2r_cdiv(Npos, 128), i2r_cdiv(Cout, 128), nsplit);
-  static bool attr_set = false;
-  const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_h2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    (void)hipFuncSetAttribute((const void*)conv_fwd_h2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-    attr_set = true;
+  dim3 grid(i2r_cdiv(Npos, bn), i2r_cdiv(Cout, 128), nsplit);
+  const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);  // two weight stages (hi + lo rows each)
+  // DPP tap reuse needs lanes = consecutive positions of one image row: W a power of two <= 32
+  const bool dpp = ksize == 3 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP");
+#define H2_LAUNCH(KS_, SP_, NW_, DP_)                                                                              \
+  do {                                                                                                             \
+    auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_>;                                                            \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                KS_ == 3 ? lds3 : lds1);                                                           \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), KS_ == 3 ? lds3 : lds1, s, p);                                  \
+  } while (0)
+#define H2_PICK_NW(KS_, SP_, DP_)            \
+  do {                                       \
+    if (bn == 256) H2_LAUNCH(KS_, SP_, 8, DP_); \
+    else H2_LAUNCH(KS_, SP_, 4, DP_);        \
+  } while (0)
+  if (ksize == 3) {
+    if (x_is_split) { if (dpp) H2_PICK_NW(3, true, true); else H2_PICK_NW(3, true, false); }
+    else { if (dpp) H2_PICK_NW(3, false, true); else H2_PICK_NW(3, false, false); }
+  } else {
+    if (x_is_split) H2_PICK_NW(1, true, false);
+    else H2_PICK_NW(1, false, false);
   }
-  if (ksize == 3)
-    hipLaunchKernelGGL(conv_fwd_h2_kernel<3>, grid, dim3(256), lds3, s, p);
-  else
-    hipLaunchKernelGGL(conv_fwd_h2_kernel<1>, grid, dim3(256), lds1, s, p);
+#undef H2_PICK_NW
+#undef H2_LAUNCH
   if (nsplit > 1) {
     long total = Npos * Cout;
     int nb = i2r_cdiv(total, 256);

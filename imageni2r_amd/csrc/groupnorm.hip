@@ -24,6 +24,14 @@ __device__ __forceinline__ uint64_t eff_offset(uint64_t offset, const uint64_t* 
   return rng_step ? offset + (rng_step[0] << 20) : offset;
 }
 
+// y -> f16 hi | f16 lo << 16 (the operand format of the split-f16 inference conv), carried in a float register
+__device__ __forceinline__ float split_pack(float y) {
+  _Float16 hi = (_Float16)y;
+  _Float16 lo = (_Float16)(y - (float)hi);
+  unsigned w = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+  return __builtin_bit_cast(float, w);
+}
+
 template <int LPG>
 __device__ __forceinline__ float seg_sum(float v) {
 #pragma unroll
@@ -52,7 +60,7 @@ struct GnP {
   float* dgb_part;      // backward: (B, 2C) per-sample [dgamma | dbeta]
   float* dss;           // backward: (B, 2C) [dscale | dshift]
   const uint64_t* rng_step;
-  int ss_batch, B, C, HW, G, sh, act;
+  int ss_batch, B, C, HW, G, sh, act, split_out;
   float eps, drop_p;
   uint64_t seed, offset;
 };
@@ -119,6 +127,10 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
       u[1] *= keep_of(r.y, p.drop_p, inv_keep);
       u[2] *= keep_of(r.z, p.drop_p, inv_keep);
       u[3] *= keep_of(r.w, p.drop_p, inv_keep);
+    }
+    if (p.split_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = split_pack(u[j]);
     }
     yp[i4] = make_float4(u[0], u[1], u[2], u[3]);
   }
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_fwd_kernel(GnP p) {
     if (ssp) u = u * (ssp[c] + 1.0f) + ssp[C + c];
     if (p.act) u = silu_f(u);
     if (p.drop_p > 0.0f) u *= keep_scale1(p.seed, off, base + i, p.drop_p);
-    p.y[base + i] = u;
+    p.y[base + i] = p.split_out ? split_pack(u) : u;
   }
 }
 
@@ -399,7 +411,7 @@ static void gn_launch(const GnP& p, hipStream_t s) {
 extern "C" int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* ss,
                                      int ss_batch, float* y, float* mean, float* rstd, int B, int C, int HW, int G,
                                      float eps, int act, float drop_p, uint64_t seed, uint64_t offset,
-                                     const uint64_t* rng_step, i2r_stream_t stream) {
+                                     const uint64_t* rng_step, int split_out, i2r_stream_t stream) {
   I2R_REQUIRE(x && gamma && beta && y, "groupnorm_fwd: null pointer");
   I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_fwd: C=%d not divisible by G=%d", C, G);
   I2R_REQUIRE((mean == nullptr) == (rstd == nullptr), "groupnorm_fwd: mean and rstd must both be given or both null");
@@ -408,7 +420,7 @@ extern "C" int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const f
   GnP p{};
   p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.y = y; p.mean_out = mean; p.rstd_out = rstd;
   p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B; p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW);
-  p.act = act; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  p.act = act; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.offset = offset; p.split_out = split_out;
   gn_launch<false>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_fwd");
 }

@@ -100,8 +100,11 @@ class Conv2d(torch.nn.Module):
             return self._wpd
         return None
 
-    def forward(self, x, residual=None):
-        """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue."""
+    def forward(self, x, residual=None, x_split=False):
+        """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue.  ``x_split``: x is the
+        pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only)."""
+        if x_split and (self.up or self.down or torch.is_grad_enabled() or ops.conv_math() != "f16x2"):
+            raise ValueError("x_split is only valid for a plain inference conv in f16x2 mode")
         if self.up:
             x = ops.Up2Fn.apply(x)
         if self.down:
@@ -109,7 +112,7 @@ class Conv2d(torch.nn.Module):
         if self.weight is not None:
             if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
-                                         None if residual is None else ops._c(residual))
+                                         None if residual is None else ops._c(residual), x_split)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -126,8 +129,13 @@ class GroupNorm(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(num_channels))
         self._rng_id = next(_layer_ids)  # fixed Philox stream id of this layer's dropout (device-step RNG mode)
 
-    def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0):
-        """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer."""
+    def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0, split_out=False):
+        """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer.
+        ``split_out`` (inference only): emit f16 hi/lo pairs for a following f16x2 conv instead of fp32."""
+        if split_out:
+            y, _, _ = ops.groupnorm_fwd(ops._c(x), self.weight, self.bias, self.num_groups, self.eps,
+                                        None if scale_shift is None else ops._c(scale_shift), act_silu, split_out=True)
+            return y
         seed = offset = 0
         if drop_p > 0.0:
             seed = torch.initial_seed() & ((1 << 63) - 1)
@@ -177,13 +185,17 @@ class UNetBlock(torch.nn.Module):
         GN+SiLU -> conv0 -> affine -> GN+mod+SiLU(+dropout) -> [skip conv] -> conv1(+residual)
         [-> GN -> qkv conv -> attention -> proj conv(+residual)]."""
         orig = x
-        x = self.conv0(self.norm0(x, act_silu=True))
+        # inference in f16x2 conv math: the norms hand the convs pre-split f16 pairs (no conversion in the conv)
+        sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
+        sp0 = sp and not (self.conv0.up or self.conv0.down)
+        x = self.conv0(self.norm0(x, act_silu=True, split_out=sp0), x_split=sp0)
         params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
-        x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0)
+        x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0,
+                       split_out=sp)
         skip = self.skip(orig) if self.skip is not None else orig
-        x = self.conv1(x, residual=skip)
+        x = self.conv1(x, residual=skip, x_split=sp)
         if self.num_heads:
-            qkv = self.qkv(self.norm2(x))
+            qkv = self.qkv(self.norm2(x, split_out=sp), x_split=sp)
             a = ops.AttentionFn.apply(qkv, self.num_heads)
             x = self.proj(a, residual=x)
         return x
@@ -313,7 +325,8 @@ class DhariwalUNet(torch.nn.Module):
             if x.shape[1] != block.in_channels:
                 x = ops.ConcatFn.apply(x, skips.pop())
             x = block(x, emb)
-        return self.out_conv(self.out_norm(x, act_silu=True))
+        sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
+        return self.out_conv(self.out_norm(x, act_silu=True, split_out=sp), x_split=sp)
 
 
 class EDMPrecond(torch.nn.Module):

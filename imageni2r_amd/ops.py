@@ -194,8 +194,9 @@ def conv2d_pack_h2(w):
     return wp
 
 
-def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None):
-    """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip)."""
+def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False):
+    """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip).  ``x_split``: x holds
+    pre-split f16 pairs (groupnorm_fwd(..., split_out=True))."""
     _chk(x, "x")
     Cout, Cin, k, _ = w_shape
     B, Cin2, H, W = x.shape
@@ -207,7 +208,7 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None):
     nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
     ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
     _lib.call("i2r_conv2d_fwd_h2", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W, Cout, k,
-              _stream())
+              int(bool(x_split)), _stream())
     return out
 
 
@@ -271,7 +272,7 @@ def split_channels(x, C1):
 
 
 def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=False, drop_p=0.0, seed=0, offset=0,
-                  step=None):
+                  step=None, split_out=False):
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
@@ -287,7 +288,8 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=Fa
         mean = torch.empty((B * groups,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
     _lib.call("i2r_groupnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), ss_batch, _p(y), _p(mean), _p(rstd), B, C,
-              HW, groups, float(eps), int(bool(act)), float(drop_p), int(seed), int(offset), _p(step), _stream())
+              HW, groups, float(eps), int(bool(act)), float(drop_p), int(seed), int(offset), _p(step),
+              int(bool(split_out)), _stream())
     return y, mean, rstd
 
 

@@ -69,9 +69,11 @@ int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* ws, long ws_flo
 long i2r_conv2d_packed_h2_bytes(int Cout, int Cin, int ksize);
 int i2r_conv2d_pack_weight_h2(const float* w /* OIHW */, void* wp, int Cout, int Cin, int ksize, i2r_stream_t stream);
 long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksize);
+/* x_is_split: the activations were already split by their producer (i2r_groupnorm_fwd_f32 with split_out): each 32-bit
+ * element holds f16 hi | f16 lo << 16 in the same NCHW positions. */
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
-                      i2r_stream_t stream);
+                      int x_is_split, i2r_stream_t stream);
 /* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) and dbias (Cout, may be NULL) are overwritten, or added to when
  * `accumulate` is set (gradient buffers zeroed once per step by the caller). */
 int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
@@ -88,10 +90,11 @@ int i2r_split_channels_f32(const float* in, float* a, float* c, int B, long n1, 
 /* ---- GroupNorm family: models/networks.py:104-106 fused with its consumers (:168, :173, :177, :182, :460) ---------- */
 /* y = dropout_p( act( gn(x; gamma, beta, G, eps) * (1 + scale) + shift ) );  ss = [scale | shift] (ss_batch, 2C) or
  * NULL; act: 0 identity, 1 SiLU; mean/rstd (B*G) optional outputs for backward; dropout mask = Philox(seed,
- * offset + (*rng_step << 20)); rng_step (device counter, see i2r_counter_add_u64) may be NULL. */
+ * offset + (*rng_step << 20)); rng_step (device counter, see i2r_counter_add_u64) may be NULL.  split_out: store each
+ * y as the pair f16 hi | f16 lo << 16 (hi = f16(y), lo = f16(y - hi)) for i2r_conv2d_fwd_h2(x_is_split). */
 int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
                           float* y, float* mean, float* rstd, int B, int C, int HW, int G, float eps, int act,
-                          float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                          float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step, int split_out,
                           i2r_stream_t stream);
 /* backward: dx (B,C,HW); dgb_part (B,2C) per-sample [dgamma | dbeta] partials (reduce with i2r_reduce_rows_f32);
  * dss (B,2C) = [dscale | dshift] iff ss given. */

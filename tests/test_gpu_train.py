@@ -101,6 +101,27 @@ def test_conv_split_f16_vs_oracle(ops, B, Cin, Cout, H, k):
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,k", [(3, 128, 128, 16, 3), (2, 256, 384, 8, 1), (5, 96, 160, 4, 3),
+                                            (2, 1024, 512, 2, 3), (2, 128, 12, 16, 3)])
+def test_groupnorm_split_out_feeds_split_conv(ops, B, Cin, Cout, H, k):
+    """GroupNorm(+SiLU+modulation) emitting f16 hi/lo pairs, consumed by the f16x2 conv with x_split: the pair of
+    kernels matches the fp64 composition to fp32-grade accuracy (the conv does no conversion of its own)."""
+    gen = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=gen) * 2.0 + 0.5
+    gw, gb = torch.randn(Cin, generator=gen), torch.randn(Cin, generator=gen)
+    ss = torch.randn(1, 2 * Cin, generator=gen) * 0.5
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=gen)
+    G = min(32, Cin // 4)
+    n = torch.nn.functional.group_norm(x.double(), G, gw.double(), gb.double(), 1e-5)
+    n = torch.nn.functional.silu(ss[:, Cin:, None, None].double() + n * (ss[:, :Cin, None, None].double() + 1))
+    ref = torch.nn.functional.conv2d(n, w.double(), b.double(), padding=k // 2)
+    ysp, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, ss=cu(ss.numpy()), act=True,
+                                  split_out=True)
+    y = ops.conv2d_fwd_h2(ysp, tuple(w.shape), ops.conv2d_pack_h2(cu(w.numpy())), cu(b.numpy()), None, x_split=True)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-6
+
+
 def _ref_tail(params, grads, state, shadows, n_upd, lr, wd, max_norm, warmup, steps):
     """torch AdamW + clip_grad_norm_ + the EMA rule of models/ema.py:26-47 on the CPU."""
     ps = [torch.nn.Parameter(p.clone()) for p in params]

@@ -13,6 +13,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imageni2r_amd import ops  # noqa: E402
 
+SHAPES_B1_1024 = [f"1024,{ci},{co},{h},{k}" for (ci, co, h, k) in
+                  [(128, 128, 16, 3), (256, 128, 16, 3), (384, 128, 16, 3), (128, 256, 8, 3), (256, 256, 8, 3),
+                   (512, 256, 8, 3), (256, 256, 4, 3), (512, 256, 4, 3), (768, 256, 4, 3), (512, 512, 2, 3),
+                   (1024, 512, 2, 3), (128, 384, 16, 1), (128, 128, 16, 1), (256, 768, 8, 1), (256, 256, 8, 1),
+                   (256, 768, 4, 1), (512, 1536, 2, 1)]]
 SHAPES_B1_256 = ["256,128,128,16,3", "256,256,256,8,3", "256,512,256,8,3", "256,256,256,4,3", "256,512,256,4,3",
                  "256,512,512,2,3", "256,1024,512,2,3", "256,256,768,8,1", "256,128,384,16,1"]
 
@@ -21,8 +26,10 @@ ap.add_argument("--shape", action="append")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--op", default="fwd")
 ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS probe)")
+ap.add_argument("--set", default="", help="named shape set: b1_1024")
+ap.add_argument("--split-in", action="store_true", help="h2: feed pre-split activations")
 a = ap.parse_args()
-shapes = a.shape or SHAPES_B1_256
+shapes = a.shape or (SHAPES_B1_1024 if a.set == "b1_1024" else SHAPES_B1_256)
 dev = "cuda"
 for sh in shapes:
     B, Cin, Cout, H, k = map(int, sh.split(","))
@@ -37,7 +44,7 @@ for sh in shapes:
         fn = lambda: ops.conv2d_fwd(x, w, b, None, wp)
     elif a.op == "h2":
         wph = ops.conv2d_pack_h2(w)
-        fn = lambda: ops.conv2d_fwd_h2(x, w.shape, wph, b, None)
+        fn = lambda: ops.conv2d_fwd_h2(x, w.shape, wph, b, None, a.split_in)
         ref = ops.conv2d_fwd(x, w, b, None)
         err = (fn() - ref).abs().max().item() / ref.abs().max().item()
         print(f"   h2 vs f32 max rel err {err:.2e}")
