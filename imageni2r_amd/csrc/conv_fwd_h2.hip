@@ -37,7 +37,7 @@ struct ConvHParams {
   unsigned x_bytes, wp_bytes;
   int B, Cin, H, W, Cout, HW, nCB;
   long Npos;
-  int chunks_per_split, nsplit;
+  int chunks_per_split, nsplit, mtiles;
   long slab_stride;
   int ablate;  // tuning only (I2R_H2_ABLATE): 1 = skip the epilogue stores, 2 = skip the main loop
 };
@@ -74,6 +74,41 @@ __device__ __forceinline__ void unpack8(const float* v, half8& hi, half8& lo) {
   lo = __builtin_bit_cast(half8, lv);
 }
 
+// Epilogue of both kernels: lane = (position, channel half h), acc[t][r] = channel m0 + 32t + (r&3) + 8(r>>2) + 4h.
+// Buffer addressing (lane voffset + per-channel scalar offset) keeps it at one address register.  Every load (bias,
+// residual) is issued BEFORE the first store: the compiler must assume the output may alias them, so a load placed
+// after a store waits for it -- interleaved, the 64 elements become 64 serial load -> wait -> store round trips
+// (measured: 25 us per workgroup, more than the whole main loop of a 1x1 conv).
+__device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
+                                            bool nvalid, unsigned pb, unsigned pos, int m0, int h, int ablate) {
+  const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
+  __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)out_bytes, 0x00020000);
+  const unsigned plane = (unsigned)p.HW * 4;
+  const unsigned voff = nvalid ? ((pb * (unsigned)p.Cout + (unsigned)(m0 + 4 * h)) * (unsigned)p.HW + pos) * 4u : OOR;
+  const int lim = p.Cout - m0 - 4 * h;  // channel offsets below lim exist
+  const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
+  float bv[4][16], rv[4][16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
+      const bool ok = cof < lim;
+      bv[t][r] = (use_bias && ok) ? p.bias[m0 + 4 * h + cof] : 0.0f;
+      rv[t][r] = use_res ? bufload(rR, ok ? voff : OOR, (unsigned)cof * plane) : 0.0f;
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
+      float v = acc[t][r] * WSCALE_INV + bv[t][r] + rv[t][r];
+      unsigned vo = (cof < lim && (!(ablate & 1) || v == 12345.678f)) ? voff : OOR;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, vo, (unsigned)cof * plane, 0);
+    }
+}
+
 // value of lane-1 / lane+1 (0 into the wave's first / last lane): DPP wave shifts, no LDS, no memory
 __device__ __forceinline__ float from_lane_below(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -107,8 +142,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * BM;
-  const long n0 = (long)blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2.  All the
+  // output-channel tiles of one position tile get ids 8 apart -> same XCD, dispatched back to back, so the
+  // activation tile they share is fetched from HBM once and then served by that XCD's L2.  (Speed only: any
+  // placement computes the same result.)
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int mt = q % p.mtiles;
+  const long nt = (long)(q / p.mtiles) * 8 + xcd;
+  const int m0 = mt * BM;
+  const long n0 = nt * BN;
+  if (n0 >= p.Npos) return;  // padding of the position-tile count to a multiple of 8 (whole workgroup exits)
 
   __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -298,25 +341,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 
   const bool direct = p.nsplit == 1;
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
-  if (nvalid) {
-    const int pos = (int)(nj % p.HW);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int co = m0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < p.Cout) {
-          long o = ((long)pb * p.Cout + co) * p.HW + pos;
-          float v = acc[t][r] * WSCALE_INV;
-          if (direct) {
-            if (p.bias) v += p.bias[co];
-            if (p.res) v += p.res[o];
-          }
-          if (!(p.ablate & 1) || v == 12345.678f) outp[o] = v;
-        }
-      }
-    }
-  }
+  h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate);
 }
 
 // out = sum_z slab[z] + bias + residual
@@ -421,9 +446,10 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_fwd_h2: non-positive dimension");
   long x_bytes = (long)B * Cin * H * W * 4;
   long wp_bytes = i2r_conv2d_packed_h2_bytes(Cout, Cin, ksize);
-  I2R_REQUIRE(x_bytes < 0x7FFFFFFFL && wp_bytes < 0x7FFFFFFFL,
-              "conv2d_fwd_h2: input (%ld B) or packed weights (%ld B) exceed the 2 GiB buffer-addressing limit",
-              x_bytes, wp_bytes);
+  long out_bytes = (long)B * Cout * H * W * 4;
+  I2R_REQUIRE(x_bytes < 0x7FFFFFFFL && wp_bytes < 0x7FFFFFFFL && out_bytes < 0x7FFFFFFFL,
+              "conv2d_fwd_h2: input (%ld B), output (%ld B) or packed weights (%ld B) exceed the 2 GiB "
+              "buffer-addressing limit; split the batch", x_bytes, out_bytes, wp_bytes);
   long Npos = (long)B * H * W;
   int chunks = h2_chunks(Cin, ksize), bn, nsplit, cps;
   h2_plan(Npos, Cout, chunks, splitk_ws != nullptr, bn, nsplit, cps);
@@ -436,7 +462,8 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(i2r_cdiv(Npos, bn), i2r_cdiv(Cout, 128), nsplit);
+  p.mtiles = i2r_cdiv(Cout, 128);
+  dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);
   const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);  // two weight stages (hi + lo rows each)
   // DPP tap reuse needs lanes = consecutive positions of one image row: W a power of two <= 32
   const bool dpp = ksize == 3 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP");
