@@ -166,28 +166,33 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Conv2Params p) {
 
   // epilogue: C/D layout col = lane&31 (position), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output channel)
   if (p.ablate & 8) return;
+  // Bias and residual are loaded for the whole tile BEFORE the first store: the output may alias them as far as the
+  // compiler knows, so a load placed after a store would wait for it (64 serial round trips per lane otherwise).
   const bool direct = p.nsplit == 1;
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
+  const bool use_bias = direct && p.bias != nullptr, use_res = direct && p.res != nullptr;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     long n = n0 + (wn * TN + tn) * 32 + l31;
-    if (n >= p.Npos) continue;
-    int b = (int)(n / p.HW);
-    int pos = (int)(n % p.HW);
+    const bool nok = n < p.Npos;
+    int b = nok ? (int)(n / p.HW) : 0;
+    int pos = nok ? (int)(n % p.HW) : 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      float add[16];  // one 32x32 sub-tile at a time keeps the register footprint of the main loop
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < p.Cout) {
-          long o = ((long)b * p.Cout + co) * p.HW + pos;
-          float v = acc[tm][tn][r];
-          if (direct) {
-            if (p.bias) v += p.bias[co];
-            if (p.res) v += p.res[o];
-          }
-          outp[o] = v;
-        }
+        bool ok = nok && co < p.Cout;
+        long o = ((long)b * p.Cout + co) * p.HW + pos;
+        float a = (use_bias && ok) ? p.bias[co] : 0.0f;
+        if (use_res && ok) a += p.res[o];
+        add[r] = a;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (nok && co < p.Cout) outp[((long)b * p.Cout + co) * p.HW + pos] = acc[tm][tn][r] + add[r];
       }
     }
   }
