@@ -137,6 +137,178 @@ __global__ __launch_bounds__(64) void attn_fwd_small_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------ inference forward on the f16 MFMA
+// Same flash structure with every product on the HALF-precision matrix cores at fp32-grade accuracy (the "f16x2
+// split" of conv_fwd_h2.hip: x = hi + lo in fp16, a*b = a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate): 24
+// v_mfma_f32_32x32x16_f16 (768 cycles) per 32-key tile instead of 64 v_mfma_f32_32x32x2_f32 (4096 cycles).
+//   S^T = K^T Q : A = K^T tile from LDS ([key][d] rows, 16-B fragments), B = Q fragments held in registers.
+//   O  += V P   : B = P straight from the S accumulator (registers 8s..8s+7 -> k-step s; element j of lane half h is
+//                 key 16s + 8(j>>2) + 4h + (j&3)), A = V tile from an LDS image stored in exactly that key order.
+// K/V tiles are split to fp16 hi/lo once, while being staged (double buffered, one barrier per tile).
+typedef _Float16 ah8 __attribute__((ext_vector_type(8)));
+typedef unsigned au4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void a_split8(const float* v, ah8& hi, ah8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 hh, ll;
+    f16_split(v[j], hh, ll);
+    hi[j] = hh;
+    lo[j] = ll;
+  }
+}
+
+#define AKROW 144  // bytes per key row of the K image: 64 d x 2 B + 16 pad (odd multiple of 16 B)
+#define AVROW 80   // bytes per channel row of the V image: 32 keys x 2 B + 16 pad
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              int heads, int T) {
+  constexpr int NT = 64 * QW, NIT = 256 / NT;                 // staging work items per thread
+  constexpr int KBYTES = KT * AKROW, VBYTES = HD * AVROW;     // one of hi / lo
+  constexpr int STAGE = 2 * KBYTES + 2 * VBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;  // row (d, s) at base + (3 d + s) T
+  const int q0 = (blockIdx.x * QW + wave) * 32;
+
+  // Q fragments, pre-scaled by 1/sqrt(64) * log2(e) so the softmax runs on exp2
+  ah8 qh[4], ql[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = base[(long)(3 * (16 * s + 8 * h + j) + 0) * T + q0 + l31] * 0.18033688011112042f;
+    a_split8(v, qh[s], ql[s]);
+  }
+
+  f32x16 O[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[t][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  // staging: item = (key, d-group of 8) for K; (channel, piece = k-step s2, half h2) for V
+  float kreg[NIT][8];
+  float4 vreg[NIT][2];
+  auto stage_load = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int item = tid + NT * it;
+      int key = item & 31, dg = item >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kreg[it][j] = base[(long)(3 * (8 * dg + j) + 1) * T + k0 + key];
+      int c = item >> 2, piece = item & 3, s2 = piece >> 1, h2 = piece & 1;
+      const float* vp = base + (long)(3 * c + 2) * T + k0 + 16 * s2 + 4 * h2;
+      vreg[it][0] = *reinterpret_cast<const float4*>(vp);
+      vreg[it][1] = *reinterpret_cast<const float4*>(vp + 8);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    unsigned char* st = lds + buf * STAGE;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int item = tid + NT * it;
+      int key = item & 31, dg = item >> 5;
+      ah8 hi, lo;
+      a_split8(kreg[it], hi, lo);
+      *reinterpret_cast<ah8*>(st + key * AKROW + dg * 16) = hi;
+      *reinterpret_cast<ah8*>(st + KBYTES + key * AKROW + dg * 16) = lo;
+      int c = item >> 2, piece = item & 3;
+      float vv[8] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w,
+                     vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+      a_split8(vv, hi, lo);
+      *reinterpret_cast<ah8*>(st + 2 * KBYTES + c * AVROW + piece * 16) = hi;
+      *reinterpret_cast<ah8*>(st + 2 * KBYTES + VBYTES + c * AVROW + piece * 16) = lo;
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const int ntiles = T / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const unsigned char* st = lds + (kt & 1) * STAGE;
+    if (kt + 1 < ntiles) stage_load((kt + 1) * KT);
+    // ---- S^T = K^T Q  (rows = keys, cols = this lane's query)
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ah8 kh = *reinterpret_cast<const ah8*>(st + l31 * AKROW + s * 32 + h * 16);
+      ah8 kl = *reinterpret_cast<const ah8*>(st + KBYTES + l31 * AKROW + s * 32 + h * 16);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+    }
+    // ---- online softmax in base 2 (scores are already in log2 units)
+    float mt = sacc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float m_new = fmaxf(m_run, mt);
+    float alpha = exp2f(m_run - m_new);
+    float psum = 0.0f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = exp2f(sacc[r] - m_new);
+      psum += pv[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+    // ---- O += V P
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ah8 ph, pl;
+      a_split8(pv + 8 * s, ph, pl);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned char* vrow = st + 2 * KBYTES + (t * 32 + l31) * AVROW + (2 * s + h) * 16;
+        ah8 vh = *reinterpret_cast<const ah8*>(vrow);
+        ah8 vl = *reinterpret_cast<const ah8*>(vrow + VBYTES);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, O[t], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < ntiles) stage_store((kt + 1) & 1);  // the other stage: its readers finished before the last barrier
+    __syncthreads();
+  }
+  float inv_l = 1.0f / l_run;
+  float* ob = out + ((long)b * C + (long)hd * HD) * T;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      ob[(long)c * T + q0 + l31] = O[t][r] * inv_l;
+    }
+}
+
+// f16x2-split inference forward; T must be a multiple of 32 and > 32 (smaller T: i2r_attention_fwd_f32's LDS kernel).
+extern "C" int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, i2r_stream_t stream) {
+  I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 32 && T % 32 == 0, "attention_fwd_h2: bad argument (T=%d)", T);
+  I2R_REQUIRE((((uintptr_t)qkv) & 15) == 0, "attention_fwd_h2: qkv must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (T % 128 == 0)
+    hipLaunchKernelGGL(attn_fwd_h2_kernel<4>, dim3(T / 128, B * heads), dim3(256), 0, s, qkv, out, heads, T);
+  else if (T % 64 == 0)
+    hipLaunchKernelGGL(attn_fwd_h2_kernel<2>, dim3(T / 64, B * heads), dim3(128), 0, s, qkv, out, heads, T);
+  else
+    hipLaunchKernelGGL(attn_fwd_h2_kernel<1>, dim3(T / 32, B * heads), dim3(64), 0, s, qkv, out, heads, T);
+  return i2r_check_launch("attention_fwd_h2");
+}
+
 extern "C" int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T,
                                      i2r_stream_t stream) {
   I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention_fwd: bad argument");

@@ -53,9 +53,10 @@ __device__ __forceinline__ uint4v bufload4(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    _Float16 h = (_Float16)v[j];
+    _Float16 h, l;
+    f16_split(v[j], h, l);
     hi[j] = h;
-    lo[j] = (_Float16)(v[j] - (float)h);
+    lo[j] = l;
   }
 }
 
@@ -378,8 +379,8 @@ __global__ void pack_weight_h2_kernel(const float* __restrict__ w, _Float16* __r
       if (c < Cin) v = w[(long)co * Cin + c];
     }
     v *= WSCALE;
-    _Float16 hi = (_Float16)v;
-    _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16 hi, lo;
+    f16_split(v, hi, lo);
     long base = ((long)chunk * Cout + co) * 2 * KC;
     wp[base + k] = hi;
     wp[base + KC + k] = lo;

@@ -26,8 +26,8 @@ __device__ __forceinline__ uint64_t eff_offset(uint64_t offset, const uint64_t* 
 
 // y -> f16 hi | f16 lo << 16 (the operand format of the split-f16 inference conv), carried in a float register
 __device__ __forceinline__ float split_pack(float y) {
-  _Float16 hi = (_Float16)y;
-  _Float16 lo = (_Float16)(y - (float)hi);
+  _Float16 hi, lo;
+  f16_split(y, hi, lo);
   unsigned w = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
   return __builtin_bit_cast(float, w);
 }

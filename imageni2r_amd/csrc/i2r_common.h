@@ -50,6 +50,16 @@ __device__ __forceinline__ float dsilu_f(float u) {
   return s * (1.0f + u * (1.0f - s));
 }
 
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): the operand split of the f16x2 kernels.  The value is made opaque
+// first: when x is the result of a multiply, hipcc folds f16(a*b) into v_fma_mixlo_f16 (ONE rounding of the exact
+// product) for the stored hi but may convert the separately rounded f32 product for the subtraction -- at an exact
+// f16 tie the two disagree by one f16 ulp and hi + lo is off by 2^-11 |x| (seen in the attention Q scaling).
+__device__ __forceinline__ void f16_split(float x, _Float16& hi, _Float16& lo) {
+  asm volatile("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
 // Philox4x32-10 counter RNG (used for dropout keep-masks and training noise; regenerated, never stored)
 __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

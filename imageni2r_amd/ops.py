@@ -320,6 +320,9 @@ def attention_fwd(qkv, heads, save_lse=False):
         raise ValueError(f"attention: channels {C} != heads*64 ({heads}*64); head dim is fixed at 64")
     T = qkv.numel() // (B * C3)
     out = torch.empty((B, C) + tuple(qkv.shape[2:]), dtype=torch.float32, device=qkv.device)
+    if not save_lse and conv_math() == "f16x2" and T > 32 and T % 32 == 0:
+        _lib.call("i2r_attention_fwd_h2", _p(qkv), _p(out), B, heads, T, _stream())  # inference: f16x2-split MFMA
+        return out, None
     lse = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device) if save_lse else None
     _lib.call("i2r_attention_fwd_f32", _p(qkv), _p(out), _p(lse), B, heads, T, _stream())
     return out, lse

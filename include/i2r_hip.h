@@ -110,6 +110,9 @@ int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, 
 /* ---- attention: models/networks.py:113-126 (AttentionOp) + :182-184 ---------------------------------------------- */
 /* qkv (B, 3*heads*64, T) interleaved (head, d, {q,k,v}); out (B, heads*64, T); lse (B*heads*T) optional (backward). */
 int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T, i2r_stream_t stream);
+/* inference forward of the same op on the f16 matrix cores with fp32-grade accuracy (f16x2 split, see
+ * i2r_conv2d_fwd_h2); T a multiple of 32 and > 32; qkv 16-byte aligned. */
+int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, i2r_stream_t stream);
 /* AttentionOp.backward (:121-126) + einsum backward: dqkv (B,3C,T); delta_ws: workspace of B*heads*T floats. */
 int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                           float* delta_ws, int B, int heads, int T, i2r_stream_t stream);
