@@ -409,16 +409,17 @@ extern "C" int i2r_conv2d_pack_weight_h2(const float* w, void* wp, int Cout, int
 
 // positions per workgroup: 256 (8 waves, one workgroup per CU) once that still gives every CU >= 2 workgroups of work,
 // else 128 (4 waves, two workgroups per CU)
-static int h2_bn(long Npos, int Cout) {
+static int h2_bn(long Npos, int Cout, int ksize) {
   if (const char* ev = getenv("I2R_H2_BN")) {  // tuning/debug override
     int v = atoi(ev);
     if (v == 128 || v == 256) return v;
   }
+  if (ksize == 1) return 128;  // short K loops: two independent workgroups per CU overlap better (measured)
   return ((long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= 512) ? 256 : 128;
 }
 
-static void h2_plan(long Npos, int Cout, int chunks, bool allow_split, int& bn, int& nsplit, int& cps) {
-  bn = h2_bn(Npos, Cout);
+static void h2_plan(long Npos, int Cout, int ksize, int chunks, bool allow_split, int& bn, int& nsplit, int& cps) {
+  bn = h2_bn(Npos, Cout, ksize);
   long tiles = (long)i2r_cdiv(Npos, bn) * i2r_cdiv(Cout, 128);
   nsplit = 1;
   if (allow_split && tiles < 256) {
@@ -435,7 +436,7 @@ static void h2_plan(long Npos, int Cout, int chunks, bool allow_split, int& bn, 
 extern "C" long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksize) {
   int bn, nsplit, cps;
   long Npos = (long)B * H * W;
-  h2_plan(Npos, Cout, h2_chunks(Cin, ksize), true, bn, nsplit, cps);
+  h2_plan(Npos, Cout, ksize, h2_chunks(Cin, ksize), true, bn, nsplit, cps);
   return nsplit > 1 ? (long)nsplit * Npos * Cout : 0;
 }
 
@@ -453,7 +454,7 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
               "buffer-addressing limit; split the batch", x_bytes, out_bytes, wp_bytes);
   long Npos = (long)B * H * W;
   int chunks = h2_chunks(Cin, ksize), bn, nsplit, cps;
-  h2_plan(Npos, Cout, chunks, splitk_ws != nullptr, bn, nsplit, cps);
+  h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr, bn, nsplit, cps);
   if (nsplit > 1 && (long)nsplit * Npos * Cout > splitk_floats) { nsplit = 1; cps = chunks; }
   ConvHParams p;
   p.x = x; p.wp = wp; p.bias = bias; p.res = residual;

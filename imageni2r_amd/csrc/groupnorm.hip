@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
     }
     if (p.act) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) u[j] = silu_f(u[j]);
+      for (int j = 0; j < 4; ++j) u[j] = silu_fast(u[j]);
     }
     if (p.drop_p > 0.0f) {
       uint4 r = keep_bits(p.seed, off, base / 4 + i4);
