@@ -34,12 +34,14 @@ SIGNATURES = {
     "i2r_conv2d_pack_weight_h2": [P, P, I, I, I, P],
     "i2r_conv2d_splitk_h2_floats": [I, I, I, I, I, I],
     "i2r_conv2d_fwd_h2": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, P],
+    "i2r_conv1x1_cat_fwd_h2": [P, P, I, I, P, P, P, P, P, L, I, I, I, I, P],
     "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
     "i2r_up2_f32": [P, P, L, I, I, F, P],
     "i2r_concat_channels_f32": [P, P, P, I, L, L, P],
     "i2r_split_channels_f32": [P, P, P, I, L, L, I, P],
     "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P, I, P],
+    "i2r_groupnorm_cat_fwd_f32": [P, P, I, I, P, P, P, I, P, I, I, I, F, I, I, P],
     "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
     "i2r_reduce_rows_f32": [P, P, I, I, P],
     "i2r_reduce_rows2_f32": [P, P, P, I, I, I, P],

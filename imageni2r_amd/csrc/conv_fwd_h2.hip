@@ -29,13 +29,14 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 #define WSCALE_INV 0.015625f
 
 struct ConvHParams {
-  const float* x;       // activations (B, Cin, H, W) fp32
+  const float* x;       // activations (B, Cin, H, W) fp32 -- or the first Cin1 channels of a virtual channel concat
+  const float* x2;      // 1x1 only: the remaining Cin - Cin1 channels (B, Cin - Cin1, H, W), or null
   const void* wp;       // packed split weights: [chunk][Cout][2][KC] f16
   const float* bias;
   const float* res;
   float* out;
-  unsigned x_bytes, wp_bytes;
-  int B, Cin, H, W, Cout, HW, nCB;
+  unsigned x_bytes, x2_bytes, wp_bytes;
+  int B, Cin, Cin1, H, W, Cout, HW, nCB;
   long Npos;
   int chunks_per_split, nsplit, mtiles;
   long slab_stride;
@@ -197,9 +198,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
       }
     }
   };
+  // 1x1 over torch.cat([x, x2], dim=1) without materialising it (models/networks.py:458): channel blocks below Cin1
+  // come from x, the rest from x2 (Cin1 is a multiple of 16, so a k-step never straddles the two).
+  __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)p.x2_bytes, 0x00020000);
+  unsigned voffB2 = OOR;
   if (KS == 1) {
-    long off = ((long)pb * p.Cin + 8 * h) * p.HW + py * p.W + px;
+    long off = ((long)pb * p.Cin1 + 8 * h) * p.HW + py * p.W + px;
     voffB[0] = nvalid ? (unsigned)(off * 4) : OOR;
+    long off2 = ((long)pb * (p.Cin - p.Cin1) + 8 * h) * p.HW + py * p.W + px;
+    voffB2 = (nvalid && p.x2) ? (unsigned)(off2 * 4) : OOR;
   }
 
   f32x16 acc[4];
@@ -239,8 +246,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          unsigned sB = (unsigned)(c * 64 + q * 16 + j) * chan_bytes + dead;
-          rb[q][j] = bufload(rB, voffB[0], sB);
+          const int cbase = c * 64 + q * 16;
+          const bool first = cbase < p.Cin1;  // wave-uniform
+          unsigned sB = (unsigned)((first ? cbase : cbase - p.Cin1) + j) * chan_bytes + dead;
+          rb[q][j] = first ? bufload(rB, voffB[0], sB) : bufload(rB2, voffB2, sB);
         }
     }
   };
@@ -440,16 +449,37 @@ extern "C" long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Co
   return nsplit > 1 ? (long)nsplit * Npos * Cout : 0;
 }
 
+static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, const float* bias,
+                     const float* residual, float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H,
+                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream);
+
 extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual,
                                  float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W,
                                  int Cout, int ksize, int x_is_split, i2r_stream_t stream) {
+  return h2_launch(x, nullptr, Cin, wp, bias, residual, out, splitk_ws, splitk_floats, B, Cin, H, W, Cout, ksize,
+                   x_is_split, stream);
+}
+
+// 1x1 convolution over the channel concatenation [x1 | x2] (C1 + C2 input channels) without materialising it.
+extern "C" int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, int C2, const void* wp,
+                                      const float* bias, const float* residual, float* out, float* splitk_ws,
+                                      long splitk_floats, int B, int H, int W, int Cout, i2r_stream_t stream) {
+  I2R_REQUIRE(x1 && x2 && C1 > 0 && C2 > 0 && C1 % 16 == 0,
+              "conv1x1_cat_fwd_h2: needs two inputs and C1 (%d) a multiple of 16", C1);
+  return h2_launch(x1, x2, C1, wp, bias, residual, out, splitk_ws, splitk_floats, B, C1 + C2, H, W, Cout, 1, 0,
+                   stream);
+}
+
+static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, const float* bias,
+                     const float* residual, float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H,
+                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream) {
   I2R_REQUIRE(x && wp && out, "conv2d_fwd_h2: null pointer");
   I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_fwd_h2: kernel size %d unsupported (1 or 3)", ksize);
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_fwd_h2: non-positive dimension");
-  long x_bytes = (long)B * Cin * H * W * 4;
+  long x_bytes = (long)B * Cin1 * H * W * 4, x2_bytes = (long)B * (Cin - Cin1) * H * W * 4;
   long wp_bytes = i2r_conv2d_packed_h2_bytes(Cout, Cin, ksize);
   long out_bytes = (long)B * Cout * H * W * 4;
-  I2R_REQUIRE(x_bytes < 0x7FFFFFFFL && wp_bytes < 0x7FFFFFFFL && out_bytes < 0x7FFFFFFFL,
+  I2R_REQUIRE(x_bytes < 0x7FFFFFFFL && x2_bytes < 0x7FFFFFFFL && wp_bytes < 0x7FFFFFFFL && out_bytes < 0x7FFFFFFFL,
               "conv2d_fwd_h2: input (%ld B), output (%ld B) or packed weights (%ld B) exceed the 2 GiB "
               "buffer-addressing limit; split the batch", x_bytes, out_bytes, wp_bytes);
   long Npos = (long)B * H * W;
@@ -457,10 +487,10 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
   h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr, bn, nsplit, cps);
   if (nsplit > 1 && (long)nsplit * Npos * Cout > splitk_floats) { nsplit = 1; cps = chunks; }
   ConvHParams p;
-  p.x = x; p.wp = wp; p.bias = bias; p.res = residual;
+  p.x = x; p.x2 = x2; p.wp = wp; p.bias = bias; p.res = residual;
   p.out = nsplit > 1 ? splitk_ws : out;
-  p.x_bytes = (unsigned)x_bytes; p.wp_bytes = (unsigned)wp_bytes;
-  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.HW = H * W; p.nCB = h2_ncb(Cin, ksize);
+  p.x_bytes = (unsigned)x_bytes; p.x2_bytes = (unsigned)(x2 ? x2_bytes : x_bytes); p.wp_bytes = (unsigned)wp_bytes;
+  p.B = B; p.Cin = Cin; p.Cin1 = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.HW = H * W; p.nCB = h2_ncb(Cin, ksize);
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   hipStream_t s = (hipStream_t)stream;

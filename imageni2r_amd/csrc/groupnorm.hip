@@ -47,7 +47,8 @@ __device__ __forceinline__ float run_sum(float v, int w) {
 }
 
 struct GnP {
-  const float* x;
+  const float* x;       // input (B, C, HW) -- or the first C1 channels of a virtual channel concat [x | x2]
+  const float* x2;      // forward only: the remaining C - C1 channels (B, C - C1, HW), or null
   const float* gamma;
   const float* beta;
   const float* ss;      // [scale | shift] (ss_batch, 2C) or null
@@ -60,7 +61,7 @@ struct GnP {
   float* dgb_part;      // backward: (B, 2C) per-sample [dgamma | dbeta]
   float* dss;           // backward: (B, 2C) [dscale | dshift]
   const uint64_t* rng_step;
-  int ss_batch, B, C, HW, G, sh, act, split_out;
+  int ss_batch, B, C, C1, HW, G, sh, act, split_out;
   float eps, drop_p;
   uint64_t seed, offset;
 };
@@ -81,7 +82,14 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int i4 = sl + LPG * k;
-    v[k] = (valid && i4 * 4 < n) ? xp[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* src = xp + i4;
+    if (p.x2) {  // torch.cat([x, x2], 1) read in place: a float4 never straddles a channel (HW >= 4)
+      int c = g * cpg + ((i4 * 4) >> p.sh), hw = (i4 * 4) & (p.HW - 1);
+      const float* q = c < p.C1 ? p.x + ((long)b * p.C1 + c) * p.HW + hw
+                                : p.x2 + ((long)b * (p.C - p.C1) + (c - p.C1)) * p.HW + hw;
+      src = reinterpret_cast<const float4*>(q);
+    }
+    v[k] = (valid && i4 * 4 < n) ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   const float mean = seg_sum<LPG>(s) / (float)n;
@@ -423,6 +431,25 @@ extern "C" int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const f
   p.act = act; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.offset = offset; p.split_out = split_out;
   gn_launch<false>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_fwd");
+}
+
+// Forward over the channel concatenation [x1 | x2] (C1 + C2 channels) without materialising it (decoder skips,
+// models/networks.py:458 followed by norm0 at :168).  Register kernels only: H*W a power of two >= 4, groups <= 4096.
+extern "C" int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                         const float* beta, const float* ss, int ss_batch, float* y, int B, int HW,
+                                         int G, float eps, int act, int split_out, i2r_stream_t stream) {
+  I2R_REQUIRE(x1 && x2 && gamma && beta && y && C1 > 0 && C2 > 0, "groupnorm_cat_fwd: bad argument");
+  const int C = C1 + C2;
+  I2R_REQUIRE(B > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_cat_fwd: C=%d not divisible by G=%d", C, G);
+  I2R_REQUIRE(!ss || ss_batch == 1 || ss_batch == B, "groupnorm_cat_fwd: scale/shift batch %d vs %d", ss_batch, B);
+  GnP p{};
+  p.x = x1; p.x2 = x2; p.C1 = C1; p.gamma = gamma; p.beta = beta; p.ss = ss; p.y = y; p.ss_batch = ss_batch;
+  p.B = B; p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW); p.act = act; p.eps = eps; p.split_out = split_out;
+  I2R_REQUIRE(p.sh >= 2 && (C / G) * HW <= 4096 && ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)y)) & 15) == 0,
+              "groupnorm_cat_fwd: needs H*W a power of two >= 4 (got %d), groups <= 4096 elements, 16-B aligned "
+              "tensors", HW);
+  gn_launch<false>(p, (hipStream_t)stream);
+  return i2r_check_launch("groupnorm_cat_fwd");
 }
 
 extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss,

@@ -105,6 +105,9 @@ class Conv2d(torch.nn.Module):
         pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only)."""
         if x_split and (self.up or self.down or torch.is_grad_enabled() or ops.conv_math() != "f16x2"):
             raise ValueError("x_split is only valid for a plain inference conv in f16x2 mode")
+        if isinstance(x, tuple):  # (x, skip): torch.cat([x, skip], 1) read in place -- inference 1x1 convs only
+            return ops.conv1x1_cat_fwd_h2(ops._c(x[0]), ops._c(x[1]), self.weight.shape, self.packed_weight_h2(),
+                                          self.bias, None if residual is None else ops._c(residual))
         if self.up:
             x = ops.Up2Fn.apply(x)
         if self.down:
@@ -132,6 +135,9 @@ class GroupNorm(torch.nn.Module):
     def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0, split_out=False):
         """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer.
         ``split_out`` (inference only): emit f16 hi/lo pairs for a following f16x2 conv instead of fp32."""
+        if isinstance(x, tuple):  # (x, skip): the decoder's channel concat, never materialised (inference only)
+            return ops.groupnorm_cat_fwd(ops._c(x[0]), ops._c(x[1]), self.weight, self.bias, self.num_groups, self.eps,
+                                         None if scale_shift is None else ops._c(scale_shift), act_silu, split_out)
         if split_out:
             y, _, _ = ops.groupnorm_fwd(ops._c(x), self.weight, self.bias, self.num_groups, self.eps,
                                         None if scale_shift is None else ops._c(scale_shift), act_silu, split_out=True)
@@ -309,6 +315,16 @@ class DhariwalUNet(torch.nn.Module):
             else:
                 c._wp, c._wp_key = v, k3
 
+    @staticmethod
+    def _cat_in_place(x, skip, block):
+        """Inference in f16x2 mode, geometry the dual-source kernels cover (H*W a power of two >= 4, C1 % 16 == 0,
+        a 1x1 skip conv): the decoder concat (:458) is not materialised."""
+        hw = x.shape[2] * x.shape[3]
+        return ((not torch.is_grad_enabled()) and ops.conv_math() == "f16x2" and hw >= 4 and (hw & (hw - 1)) == 0
+                and x.shape[1] % 16 == 0 and block.skip is not None and block.skip.weight is not None
+                and block.skip.weight.shape[-1] == 1 and not (block.conv0.up or block.conv0.down)
+                and (x.shape[1] + skip.shape[1]) // block.norm0.num_groups * hw <= 4096)
+
     def embed(self, noise_labels):
         """Noise-level embedding (:437-447): posemb -> Linear+SiLU -> Linear+SiLU."""
         emb = self.map_noise(noise_labels)
@@ -323,7 +339,11 @@ class DhariwalUNet(torch.nn.Module):
             skips.append(x)
         for block in self.dec.values():
             if x.shape[1] != block.in_channels:
-                x = ops.ConcatFn.apply(x, skips.pop())
+                skip = skips.pop()
+                if self._cat_in_place(x, skip, block):
+                    x = (x, skip)  # norm0 and the 1x1 skip conv read the two tensors in place
+                else:
+                    x = ops.ConcatFn.apply(x, skip)
             x = block(x, emb)
         sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
         return self.out_conv(self.out_norm(x, act_silu=True, split_out=sp), x_split=sp)

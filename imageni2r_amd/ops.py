@@ -212,6 +212,40 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False):
     return out
 
 
+def conv1x1_cat_fwd_h2(x1, x2, w_shape, wp, bias=None, residual=None):
+    """1x1 conv over torch.cat([x1, x2], 1) read in place (f16x2 inference kernel)."""
+    _chk(x1, "x1"); _chk(x2, "x2")
+    Cout, Cin, k, _ = w_shape
+    B, C1, H, W = x1.shape
+    C2 = x2.shape[1]
+    if k != 1 or C1 + C2 != Cin or x2.shape[0] != B or tuple(x2.shape[2:]) != (H, W):
+        raise ValueError("conv1x1_cat_fwd_h2: shape mismatch")
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x1.device)
+    if residual is not None:
+        _chk(residual, "residual")
+    nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, 1)
+    ws = torch.empty((nsk,), dtype=torch.float32, device=x1.device) if nsk > 0 else None
+    _lib.call("i2r_conv1x1_cat_fwd_h2", _p(x1), _p(x2), C1, C2, _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk,
+              B, H, W, Cout, _stream())
+    return out
+
+
+def groupnorm_cat_fwd(x1, x2, gamma, beta, groups, eps, ss=None, act=False, split_out=False):
+    """GroupNorm (+modulation, SiLU, split output) over torch.cat([x1, x2], 1) read in place."""
+    _chk(x1, "x1"); _chk(x2, "x2"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    B, C1 = x1.shape[0], x1.shape[1]
+    C2 = x2.shape[1]
+    HW = x1.numel() // (B * C1)
+    ss_batch = 0
+    if ss is not None:
+        _chk(ss, "scale_shift")
+        ss_batch = ss.shape[0]
+    y = torch.empty((B, C1 + C2) + tuple(x1.shape[2:]), dtype=torch.float32, device=x1.device)
+    _lib.call("i2r_groupnorm_cat_fwd_f32", _p(x1), _p(x2), C1, C2, _p(gamma), _p(beta), _p(ss), ss_batch, _p(y), B, HW,
+              groups, float(eps), int(bool(act)), int(bool(split_out)), _stream())
+    return y
+
+
 def conv2d_dgrad(dy, w, wpd=None):
     _chk(dy, "dy"); _chk(w, "w")
     Cout, Cin, k, _ = w.shape

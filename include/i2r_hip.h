@@ -74,6 +74,11 @@ long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksi
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       int x_is_split, i2r_stream_t stream);
+/* 1x1 convolution over torch.cat([x1, x2], dim=1) (:458 feeding a block's `skip` conv, :156-159) without materialising
+ * the concatenation; C1 a multiple of 16; weights packed for Cin = C1 + C2 by i2r_conv2d_pack_weight_h2. */
+int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, int C2, const void* wp, const float* bias,
+                           const float* residual, float* out, float* splitk_ws, long splitk_floats, int B, int H, int W,
+                           int Cout, i2r_stream_t stream);
 /* autograd w.r.t. w and bias: dw (Cout,Cin,k,k) and dbias (Cout, may be NULL) are overwritten, or added to when
  * `accumulate` is set (gradient buffers zeroed once per step by the caller). */
 int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
@@ -96,6 +101,11 @@ int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta,
                           float* y, float* mean, float* rstd, int B, int C, int HW, int G, float eps, int act,
                           float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step, int split_out,
                           i2r_stream_t stream);
+/* forward over torch.cat([x1, x2], dim=1) read in place (decoder skip connections, :458 then norm0 :168).
+ * H*W must be a power of two >= 4 and a group at most 4096 elements (all shipped configs). */
+int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                              const float* ss, int ss_batch, float* y, int B, int HW, int G, float eps, int act,
+                              int split_out, i2r_stream_t stream);
 /* backward: dx (B,C,HW); dgb_part (B,2C) per-sample [dgamma | dbeta] partials (reduce with i2r_reduce_rows_f32);
  * dss (B,2C) = [dscale | dshift] iff ss given. */
 int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,

@@ -142,6 +142,35 @@ def test_attention_split_f16_vs_oracle(ops, B, heads, H):
     assert torch.equal(a, out)
 
 
+@pytest.mark.parametrize("B,C1,C2,H,Cout", [(3, 256, 128, 8, 256), (2, 512, 512, 2, 512), (2, 256, 256, 4, 256),
+                                            (5, 128, 128, 16, 128), (2, 64, 32, 8, 64)])
+def test_concat_free_groupnorm_and_skip_conv(ops, B, C1, C2, H, Cout):
+    """Decoder skip connections without materialising torch.cat (networks.py:458): GroupNorm and the 1x1 skip conv
+    read [x | skip] in place; groups that straddle the two tensors included (C1 not a multiple of the group width)."""
+    gen = torch.Generator().manual_seed(C1 + C2 + H)
+    x1 = torch.randn(B, C1, H, H, generator=gen) * 1.3
+    x2 = torch.randn(B, C2, H, H, generator=gen) * 0.7 + 0.4
+    C = C1 + C2
+    gw, gb = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    w = torch.randn(Cout, C, 1, 1, generator=gen) / np.sqrt(C)
+    bias = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, H, generator=gen)
+    cat = torch.cat([x1, x2], 1).double()
+    G = min(32, C // 4)
+    ref_n = torch.nn.functional.silu(torch.nn.functional.group_norm(cat, G, gw.double(), gb.double(), 1e-5))
+    ref_c = torch.nn.functional.conv2d(cat, w.double(), bias.double()) + res.double()
+    a, b = cu(x1.numpy()), cu(x2.numpy())
+    y = ops.groupnorm_cat_fwd(a, b, cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True)
+    assert rel_err(y.cpu().numpy(), ref_n.numpy()) < 5e-6
+    ysp = ops.groupnorm_cat_fwd(a, b, cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True, split_out=True)
+    y1, _, _ = ops.groupnorm_fwd(cu(cat.float().numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True,
+                                 split_out=True)
+    assert torch.equal(ysp.view(torch.int32), y1.view(torch.int32))  # same bits as the single-tensor kernel
+    wd = cu(w.numpy())
+    c = ops.conv1x1_cat_fwd_h2(a, b, tuple(w.shape), ops.conv2d_pack_h2(wd), cu(bias.numpy()), cu(res.numpy()))
+    assert rel_err(c.cpu().numpy(), ref_c.numpy()) < 2e-6
+
+
 def _ref_tail(params, grads, state, shadows, n_upd, lr, wd, max_norm, warmup, steps):
     """torch AdamW + clip_grad_norm_ + the EMA rule of models/ema.py:26-47 on the CPU."""
     ps = [torch.nn.Parameter(p.clone()) for p in params]
