@@ -204,7 +204,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
                                      float* __restrict__ out, long total, int Cout, int HW) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float v = slabs[i];
-    for (int z = 1; z < nsplit; ++z) v += slabs[z * slab_stride + i];
+    int z = 1;
+    for (; z + 3 < nsplit; z += 4) {  // four independent loads in flight; summation order stays z-ascending
+      float a = slabs[z * slab_stride + i], b = slabs[(z + 1) * slab_stride + i];
+      float c = slabs[(z + 2) * slab_stride + i], d = slabs[(z + 3) * slab_stride + i];
+      v = (((v + a) + b) + c) + d;
+    }
+    for (; z < nsplit; ++z) v += slabs[z * slab_stride + i];
     if (bias) v += bias[(i / HW) % Cout];
     if (res) v += res[i];
     out[i] = v;
@@ -236,8 +242,20 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // Multi-tensor form: every conv weight of the network (forward and data-gradient layouts) in ONE launch.
 // table rows {w, wp, Cout, Cin, ksize, dgrad} (int64); blockmap {tensor, block} with PACK_BLOCK packed floats per block.
 #define PACK_BLOCK 4096
+#define PACK_LDS 8192
+__device__ __forceinline__ float pack_src(const float* __restrict__ w, int m, int k, int M, int K, int KK, int Cin,
+                                          int dgrad) {
+  if (m >= M || k >= K) return 0.0f;
+  int c = k / KK, tap = k - c * KK;
+  return dgrad ? w[((long)c * Cin + m) * KK + (KK - 1 - tap)] : w[((long)m * Cin + c) * KK + tap];
+}
+// A block owns PACK_BLOCK consecutive packed floats = a band of k-rows [k_lo, k_hi] of Wp.  It is a transpose, so the
+// band is gathered in SOURCE order (lanes along k, which is contiguous in OIHW for both layouts: forward reads
+// w[m][k_lo..k_hi], dgrad reads the (ci, tap) slab of one co back to front), staged in LDS with an odd row pitch, and
+// written out in packed order: both global sides are coalesced.
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __restrict__ table,
                                                                 const int2* __restrict__ blockmap) {
+  __shared__ float tile[PACK_LDS];
   const int2 bm = blockmap[blockIdx.x];
   const long* e = table + 6L * bm.x;
   const float* w = (const float*)e[0];
@@ -248,15 +266,26 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
   const int Kpad = (K + bkc - 1) / bkc * bkc, M4 = (M + 3) / 4 * 4;
   const long total = (long)Kpad * M4;
   const long begin = (long)bm.y * PACK_BLOCK;
-  for (long i = begin + threadIdx.x; i < begin + PACK_BLOCK && i < total; i += 256) {
-    int m = (int)(i % M4);
-    int k = (int)(i / M4);
-    float v = 0.0f;
-    if (m < M && k < K) {
-      int c = k / KK, tap = k - c * KK;
-      v = dgrad ? w[((long)c * Cin + m) * KK + (KK - 1 - tap)] : w[((long)m * Cin + c) * KK + tap];
+  long end = begin + PACK_BLOCK;
+  if (end > total) end = total;
+  const int k_lo = (int)(begin / M4), k_hi = (int)((end - 1) / M4);
+  const int rows = k_hi - k_lo + 1, pitch = M4 | 1;
+  if ((long)rows * pitch <= PACK_LDS) {
+    const int n = rows * M4;
+    for (int j = threadIdx.x; j < n; j += 256) {
+      int m = j / rows, kk = j - m * rows;
+      tile[kk * pitch + m] = pack_src(w, m, k_lo + kk, M, K, KK, Cin, dgrad);
     }
-    wp[i] = v;
+    __syncthreads();
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+      int k = (int)(i / M4), m = (int)(i - (long)k * M4);
+      wp[i] = tile[(k - k_lo) * pitch + m];
+    }
+  } else {
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+      int k = (int)(i / M4), m = (int)(i - (long)k * M4);
+      wp[i] = pack_src(w, m, k, M, K, KK, Cin, dgrad);
+    }
   }
 }
 

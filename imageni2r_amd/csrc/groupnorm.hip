@@ -352,25 +352,46 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(GnP p) {
   }
 }
 
-// out[c] = sum_r in[r][c]   (deterministic batch reduction of the per-sample dgamma/dbeta partials, bias grads ...)
-__global__ void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float acc = 0.0f;
-  for (int r = 0; r < rows; ++r) acc += in[(long)r * cols + c];
-  out[c] = acc;
+// out[c] = sum_r in[r][c]   (deterministic batch reduction of the per-sample dgamma/dbeta partials, bias grads ...).
+// One lane per column would serialise `rows` dependent load+add pairs (latency-bound at the 1-8 blocks these launch),
+// so 4 lanes share a column, each summing every 4th row with 4 independent loads in flight; the 4 partials are
+// combined in a fixed order by shuffles (deterministic).
+__device__ __forceinline__ float col_sum4(const float* __restrict__ in, int rows, int cols, int c, int sub) {
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int r = sub;
+  for (; r + 12 < rows; r += 16) {
+    float v0 = in[(long)r * cols + c], v1 = in[(long)(r + 4) * cols + c];
+    float v2 = in[(long)(r + 8) * cols + c], v3 = in[(long)(r + 12) * cols + c];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; r < rows; r += 4) a0 += in[(long)r * cols + c];
+  float acc = (a0 + a1) + (a2 + a3);
+  acc += __shfl_xor(acc, 16, 64);  // the 4 sub-lanes of a column sit 16 lanes apart (16 columns per wave)
+  acc += __shfl_xor(acc, 32, 64);
+  return acc;
+}
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 4 + wave) * 16 + (lane & 15), sub = lane >> 4;
+  const bool ok = c < cols;
+  float acc = col_sum4(in, ok ? rows : 0, cols, ok ? c : 0, sub);
+  if (ok && sub == 0) out[c] = acc;
 }
 
 // same, columns [0, cols_a) -> out_a and [cols_a, cols_a + cols_b) -> out_b (dgamma | dbeta into their own buffers)
-__global__ void reduce_rows2_kernel(const float* __restrict__ in, float* __restrict__ out_a, float* __restrict__ out_b,
-                                    int rows, int cols_a, int cols_b) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  int cols = cols_a + cols_b;
-  if (c >= cols) return;
-  float acc = 0.0f;
-  for (int r = 0; r < rows; ++r) acc += in[(long)r * cols + c];
-  if (c < cols_a) out_a[c] = acc;
-  else out_b[c - cols_a] = acc;
+__global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restrict__ in, float* __restrict__ out_a,
+                                                           float* __restrict__ out_b, int rows, int cols_a,
+                                                           int cols_b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = cols_a + cols_b;
+  const int c = (blockIdx.x * 4 + wave) * 16 + (lane & 15), sub = lane >> 4;
+  const bool ok = c < cols;
+  float acc = col_sum4(in, ok ? rows : 0, cols, ok ? c : 0, sub);
+  if (ok && sub == 0) {
+    if (c < cols_a) out_a[c] = acc;
+    else out_b[c - cols_a] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -470,7 +491,7 @@ extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const f
 
 extern "C" int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream) {
   I2R_REQUIRE(in && out && rows > 0 && cols > 0, "reduce_rows: bad argument");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(i2r_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, in, out, rows,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(i2r_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows,
                      cols);
   return i2r_check_launch("reduce_rows");
 }
@@ -478,7 +499,7 @@ extern "C" int i2r_reduce_rows_f32(const float* in, float* out, int rows, int co
 extern "C" int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, int cols_a, int cols_b,
                                     i2r_stream_t stream) {
   I2R_REQUIRE(in && out_a && out_b && rows > 0 && cols_a > 0 && cols_b > 0, "reduce_rows2: bad argument");
-  hipLaunchKernelGGL(reduce_rows2_kernel, dim3(i2r_cdiv(cols_a + cols_b, 256)), dim3(256), 0, (hipStream_t)stream, in,
+  hipLaunchKernelGGL(reduce_rows2_kernel, dim3(i2r_cdiv(cols_a + cols_b, 64)), dim3(256), 0, (hipStream_t)stream, in,
                      out_a, out_b, rows, cols_a, cols_b);
   return i2r_check_launch("reduce_rows2");
 }

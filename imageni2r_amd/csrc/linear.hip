@@ -49,12 +49,19 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmP p, int vecA, int 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   // step of 8: MFMA jj pairs A's and B's slot h with contraction index k0 + 4h + jj
-  for (int k0 = kbeg; k0 < kend; k0 += 8) {
-    float a[4], b[4];
-    load4(p.A, p.a_rs, p.a_ks, i0 + l31, p.M, k0 + 4 * h, kend, vecA, a);
-    load4(p.B, p.b_rs, p.b_ks, j0 + l31, p.N, k0 + 4 * h, kend, vecB, b);
+  // four steps' operands are requested before the first MFMA consumes any: the chain is latency-bound otherwise
+  // (kc is a multiple of 8; steps past kend load zeros)
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    float a[4][4], b[4][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b[jj], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      load4(p.A, p.a_rs, p.a_ks, i0 + l31, p.M, k0 + 8 * u + 4 * h, kend, vecA, a[u]);
+      load4(p.B, p.b_rs, p.b_ks, j0 + l31, p.N, k0 + 8 * u + 4 * h, kend, vecB, b[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jj], b[u][jj], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
