@@ -349,10 +349,13 @@ static ConvPlan conv_plan(long Npos, int Cout, int Kpad, int ks, bool allow_spli
   int chunks = Kpad / conv_bkc(ks);
   int nsplit = 1;
   if (allow_split && tiles < 512) {
-    long want = (1024 + tiles - 1) / tiles;
-    long maxs = chunks / 8;
+    static const long target = getenv("I2R_CONV_TARGET") ? atol(getenv("I2R_CONV_TARGET")) : 1024;
+    static const long minch = getenv("I2R_CONV_MINCHUNKS") ? atol(getenv("I2R_CONV_MINCHUNKS")) : 8;
+    static const long maxsplit = getenv("I2R_CONV_MAXSPLIT") ? atol(getenv("I2R_CONV_MAXSPLIT")) : 32;
+    long want = (target + tiles - 1) / tiles;
+    long maxs = chunks / minch;
     if (want > maxs) want = maxs;
-    if (want > 32) want = 32;
+    if (want > maxsplit) want = maxsplit;
     if (want > 1) nsplit = (int)want;
   }
   if (const char* ev = getenv("I2R_CONV_NSPLIT")) {  // tuning/debug override

@@ -3,6 +3,7 @@
 // The reduction runs over positions; it is split over blockIdx.z (fp32 atomics into a zeroed dW) when a single pass
 // would leave CUs idle.  The bias gradient (row sums of dY) falls out of the dY tiles the first column of workgroups
 // stages anyway.  `accumulate` adds into dW/db instead of overwriting them (the caller's pre-zeroed gradient buffer).
+#include <cstdlib>
 #include "conv_common.h"
 #include "../../include/i2r_hip.h"
 
@@ -157,7 +158,8 @@ static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   long tiles = (long)i2r_cdiv(p.K, BN) * i2r_cdiv(p.Cout, BM);
   long total_chunks = (p.Npos + BK - 1) / BK;
-  long want = (1024 + tiles - 1) / tiles;  // aim for ~4 blocks per CU
+  static const long target = getenv("I2R_WGRAD_TARGET") ? atol(getenv("I2R_WGRAD_TARGET")) : 1024;
+  long want = (target + tiles - 1) / tiles;  // aim for ~4 blocks per CU
   if (want > total_chunks / 4) want = total_chunks / 4;  // keep >= 4 chunks per split
   if (want < 1) want = 1;
   p.chunks_per_split = (int)((total_chunks + want - 1) / want);
@@ -174,6 +176,13 @@ static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, s, p);
 }
 
+// 128x128 tiles only pay once the position range is long: below that the split reduction's atomic epilogue
+// (BM*BN atomics per block) outweighs the operand reuse, and 64x64 tiles win (B1, batch 32: 19.1 -> 17.7 ms/step)
+static long wgrad_big_pos() {
+  static const long v = getenv("I2R_WGRAD_BIGPOS") ? atol(getenv("I2R_WGRAD_BIGPOS")) : 32768;
+  return v;
+}
+
 extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H,
                                     int W, int Cout, int ksize, int accumulate, i2r_stream_t stream) {
   I2R_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
@@ -186,7 +195,7 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
     launch_wgrad<1, 4, 1, 1>(p, ksize, s);
   else if (p.K <= 32)
     launch_wgrad<4, 1, 1, 1>(p, ksize, s);
-  else if ((long)i2r_cdiv(p.K, 128) * i2r_cdiv(Cout, 128) >= 8 && Cout > 64)
+  else if ((long)i2r_cdiv(p.K, 128) * i2r_cdiv(Cout, 128) >= 8 && Cout > 64 && p.Npos >= wgrad_big_pos())
     launch_wgrad<2, 2, 2, 2>(p, ksize, s);
   else
     launch_wgrad<2, 2, 1, 1>(p, ksize, s);

@@ -35,11 +35,12 @@ __device__ __forceinline__ void load4(const float* base, long rs, long ks, int i
   }
 }
 
-__global__ __launch_bounds__(256) void small_gemm_kernel(GemmP p, int vecA, int vecB) {
-  __shared__ float red[4][32][33];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void small_gemm_kernel(GemmP p, int vecA, int vecB) {
+  __shared__ float red[NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  int kc = (p.K + 3) / 4;
+  int kc = (p.K + NW - 1) / NW;
   kc = (kc + 7) & ~7;  // contraction slice per wave, multiple of the 8-deep step
   const int kbeg = wave * kc;
   int kend = kbeg + kc;
@@ -67,12 +68,14 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(GemmP p, int vecA, int 
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int idx = tid + 256 * q;
+  for (int q = 0; q < 16 / NW; ++q) {
+    int idx = tid + 64 * NW * q;
     int r = idx >> 5, c = idx & 31;
     int i = i0 + r, j = j0 + c;
     if (i < p.M && j < p.N) {
-      float v = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+      float v = red[0][r][c];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += red[w][r][c];
       if (p.bias) v += p.bias[j];
       long o = (long)i * p.N + j;
       if (p.pre) p.pre[o] = v;
@@ -92,8 +95,14 @@ static bool vec_ok(const float* ptr, long rs, long ks) {
 
 static void launch_gemm(const GemmP& p, hipStream_t s) {
   dim3 grid(i2r_cdiv(p.N, 32), i2r_cdiv(p.M, 32));
-  hipLaunchKernelGGL(small_gemm_kernel, grid, dim3(256), 0, s, p, (int)vec_ok(p.A, p.a_rs, p.a_ks),
-                     (int)vec_ok(p.B, p.b_rs, p.b_ks));
+  // few output tiles and a long contraction (batch-row products against a whole weight matrix): 16 wavefronts split
+  // the contraction so every operand is requested in one round trip; otherwise 4
+  if ((long)grid.x * grid.y <= 128 && p.K >= 256)
+    hipLaunchKernelGGL(small_gemm_kernel<16>, grid, dim3(1024), 0, s, p, (int)vec_ok(p.A, p.a_rs, p.a_ks),
+                       (int)vec_ok(p.B, p.b_rs, p.b_ks));
+  else
+    hipLaunchKernelGGL(small_gemm_kernel<4>, grid, dim3(256), 0, s, p, (int)vec_ok(p.A, p.a_rs, p.a_ks),
+                       (int)vec_ok(p.B, p.b_rs, p.b_ks));
 }
 
 extern "C" int i2r_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, float* pre, int M,
