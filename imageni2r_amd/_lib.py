@@ -11,7 +11,7 @@ import os
 from ctypes import c_double, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libi2r_hip.so")
+LIB_PATH = os.environ.get("I2R_LIB_PATH") or os.path.join(_HERE, "csrc", "libi2r_hip.so")  # override: tuning builds
 
 P, I, L, F, D, U = c_void_p, c_int, c_long, c_float, c_double, c_uint64
 

@@ -87,7 +87,8 @@ def test_groupnorm_dropout_device_step(ops):
                                             (2, 12, 128, 16, 3), (2, 128, 12, 16, 3), (2, 256, 768, 8, 1),
                                             (5, 321, 128, 16, 3), (2, 128, 321, 16, 3), (3, 256, 256, 1, 3),
                                             (2, 768, 256, 4, 1), (33, 64, 96, 4, 3), (1, 7, 128, 32, 3),
-                                            (2, 13, 40, 4, 1)])
+                                            (2, 13, 40, 4, 1), (3, 128, 384, 16, 1), (3, 128, 256, 5, 1),
+                                            (5, 256, 512, 3, 1)])
 def test_conv_split_f16_vs_oracle(ops, B, Cin, Cout, H, k):
     """The inference conv on the f16 matrix cores (x = hi + lo split, 3 MFMAs) holds the fp32 bar on every tile edge."""
     gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
@@ -102,7 +103,8 @@ def test_conv_split_f16_vs_oracle(ops, B, Cin, Cout, H, k):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,k", [(3, 128, 128, 16, 3), (2, 256, 384, 8, 1), (5, 96, 160, 4, 3),
-                                            (2, 1024, 512, 2, 3), (2, 128, 12, 16, 3)])
+                                            (2, 1024, 512, 2, 3), (2, 128, 12, 16, 3), (3, 128, 384, 16, 1),
+                                            (3, 128, 256, 5, 1)])
 def test_groupnorm_split_out_feeds_split_conv(ops, B, Cin, Cout, H, k):
     """GroupNorm(+SiLU+modulation) emitting f16 hi/lo pairs, consumed by the f16x2 conv with x_split: the pair of
     kernels matches the fp64 composition to fp32-grade accuracy (the conv does no conversion of its own)."""
