@@ -43,6 +43,7 @@ SIGNATURES = {
     "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P, I, P],
     "i2r_groupnorm_cat_fwd_f32": [P, P, I, I, P, P, P, I, P, I, I, I, F, I, I, P],
     "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
+    "i2r_groupnorm_bwd_acc_f32": [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
     "i2r_reduce_rows_f32": [P, P, I, I, P],
     "i2r_reduce_rows2_f32": [P, P, P, I, I, I, P],
     "i2r_attention_fwd_f32": [P, P, P, I, I, I, P],
@@ -51,6 +52,7 @@ SIGNATURES = {
     "i2r_pos_embedding_f32": [P, P, I, I, I, P],
     "i2r_linear_fwd_f32": [P, P, P, P, P, I, I, I, I, P],
     "i2r_linear_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
+    "i2r_gemm_grouped_f32": [P, P, I, I, P, P, I, I, P],
     "i2r_silu_bwd_f32": [P, P, P, L, P],
     "i2r_add_f32": [P, P, P, L, P],
     "i2r_edm_scale_input": [P, I, P, I, P, P, I, L, F, P],

@@ -58,7 +58,9 @@ struct GnP {
   float* y;             // forward output / backward dx
   float* mean_out;
   float* rstd_out;
-  float* dgb_part;      // backward: (B, 2C) per-sample [dgamma | dbeta]
+  float* dgb_part;      // backward: (B, 2C) per-sample [dgamma | dbeta]  (or null when dg_acc / db_acc are given)
+  float* dg_acc;        // backward: (C) dgamma / dbeta accumulated with fp32 atomics over the batch (pre-zeroed by
+  float* db_acc;        //           the caller: the step's gradient slots) -- saves the (B, 2C) partials + a reduction
   float* dss;           // backward: (B, 2C) [dscale | dshift]
   const uint64_t* rng_step;
   int ss_batch, B, C, C1, HW, G, sh, act, split_out;
@@ -222,8 +224,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
         }
       }
       if (in && (sl & (runw - 1)) == 0) {
-        p.dgb_part[(long)b * 2 * p.C + c] = r_dnx;
-        p.dgb_part[(long)b * 2 * p.C + p.C + c] = r_dn;
+        if (p.dg_acc) {
+          atomicAdd(p.dg_acc + c, r_dnx);
+          atomicAdd(p.db_acc + c, r_dn);
+        } else {
+          p.dgb_part[(long)b * 2 * p.C + c] = r_dnx;
+          p.dgb_part[(long)b * 2 * p.C + p.C + c] = r_dn;
+        }
       }
       a_du = a_dun = a_dn = a_dnx = 0.0f;
     }
@@ -324,8 +331,13 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(GnP p) {
     a_dn = wave_sum(a_dn);
     a_dnx = wave_sum(a_dnx);
     if (lane == 0) {
-      p.dgb_part[(long)b * 2 * C + c] = a_dnx;
-      p.dgb_part[(long)b * 2 * C + C + c] = a_dn;
+      if (p.dg_acc) {
+        atomicAdd(p.dg_acc + c, a_dnx);
+        atomicAdd(p.db_acc + c, a_dn);
+      } else {
+        p.dgb_part[(long)b * 2 * C + c] = a_dnx;
+        p.dgb_part[(long)b * 2 * C + C + c] = a_dn;
+      }
       if (p.dss) {
         p.dss[(long)b * 2 * C + c] = a_dun;      // d scale
         p.dss[(long)b * 2 * C + C + c] = a_du;   // d shift
@@ -487,6 +499,26 @@ extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const f
   p.G = G; p.sh = pow2_shift(HW); p.act = act; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   gn_launch<true>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_bwd");
+}
+
+// Same, with dgamma / dbeta ADDED into caller-zeroed (C) buffers by fp32 atomics (32 adds per address at batch 32):
+// no (B, 2C) partial tensor and no reduction launch.  Summation order over the batch is not fixed.
+extern "C" int i2r_groupnorm_bwd_acc_f32(const float* x, const float* gamma, const float* beta, const float* ss,
+                                         int ss_batch, const float* mean, const float* rstd, const float* dy,
+                                         float* dx, float* dgamma_acc, float* dbeta_acc, float* dss, int B, int C,
+                                         int HW, int G, int act, float drop_p, uint64_t seed, uint64_t offset,
+                                         const uint64_t* rng_step, i2r_stream_t stream) {
+  I2R_REQUIRE(x && gamma && beta && mean && rstd && dy && dx && dgamma_acc && dbeta_acc,
+              "groupnorm_bwd_acc: null pointer");
+  I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_bwd_acc: C=%d not divisible by G=%d", C, G);
+  I2R_REQUIRE(!ss || ss_batch == B, "groupnorm_bwd_acc: scale/shift must be per-sample (batch %d vs %d)", ss_batch, B);
+  I2R_REQUIRE((ss != nullptr) == (dss != nullptr), "groupnorm_bwd_acc: dss must be given iff ss is");
+  GnP p{};
+  p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.mean_in = mean; p.rstd_in = rstd; p.dy = dy; p.y = dx;
+  p.dg_acc = dgamma_acc; p.db_acc = dbeta_acc; p.dss = dss; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B;
+  p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW); p.act = act; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  gn_launch<true>(p, (hipStream_t)stream);
+  return i2r_check_launch("groupnorm_bwd_acc");
 }
 
 extern "C" int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream) {

@@ -36,10 +36,10 @@ __device__ __forceinline__ void load4(const float* base, long rs, long ks, int i
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void small_gemm_kernel(GemmP p, int vecA, int vecB) {
+__device__ __forceinline__ void gemm_tile(const GemmP& p, int vecA, int vecB, int bx, int by) {
   __shared__ float red[NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int i0 = by * 32, j0 = bx * 32;
   int kc = (p.K + NW - 1) / NW;
   kc = (kc + 7) & ~7;  // contraction slice per wave, multiple of the 8-deep step
   const int kbeg = wave * kc;
@@ -82,11 +82,54 @@ __global__ __launch_bounds__(64 * NW) void small_gemm_kernel(GemmP p, int vecA, 
       p.C[o] = p.act ? silu_f(v) : v;
     }
   }
-  if (p.rowsum && blockIdx.x == 0 && tid < 32 && i0 + tid < p.M) {
+  if (p.rowsum && bx == 0 && tid < 32 && i0 + tid < p.M) {
     float s = 0.0f;
     for (int k = 0; k < p.K; ++k) s += p.A[(long)(i0 + tid) * p.a_rs + (long)k * p.a_ks];
     p.rowsum[i0 + tid] = s;
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void small_gemm_kernel(GemmP p, int vecA, int vecB) {
+  gemm_tile<NW>(p, vecA, vecB, blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ bool vec_ok_dev(const float* ptr, long rs, long ks) {
+  return ks == 1 && (rs % 4) == 0 && (((uintptr_t)ptr) & 15) == 0;
+}
+
+// All the `affine` layers of the network (models/networks.py:170, one Linear(4M -> 2 Cout) per UNetBlock, every one a
+// function of the same embedding) in ONE launch per product instead of one per layer:
+//   mode 0  y_l  (M, N_l) = emb W_l^T + b_l                          -> out_base + off_l
+//   mode 1  dW_l (N_l, K) = dy_l^T emb,  db_l = column sums of dy_l   (dy_l at base + off_l)
+//   mode 2  partial dx_l (M, K) = dy_l W_l                           -> part_base + l * M * K  (summed by reduce_rows)
+// table rows {W, bias, dW, db, N, off} (int64); blockmap {layer, tile x, tile y, -}.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(const long* __restrict__ table,
+                                                           const int4* __restrict__ blockmap, const float* emb,
+                                                           float* base, int M, int K) {
+  const int4 bm = blockmap[blockIdx.x];
+  const long* e = table + 6L * bm.x;
+  const float* W = (const float*)e[0];
+  const float* bias = (const float*)e[1];
+  float* dW = (float*)e[2];
+  float* db = (float*)e[3];
+  const int N = (int)e[4];
+  float* slab = base + e[5];
+  float* part = base + (long)bm.w;
+  GemmP p;
+  if (MODE == 0) {
+    p.A = emb; p.B = W; p.bias = bias; p.C = slab; p.pre = nullptr; p.rowsum = nullptr;
+    p.M = M; p.N = N; p.K = K; p.a_rs = K; p.a_ks = 1; p.b_rs = K; p.b_ks = 1;
+  } else if (MODE == 1) {
+    p.A = slab; p.B = emb; p.bias = nullptr; p.C = dW; p.pre = nullptr; p.rowsum = db;
+    p.M = N; p.N = K; p.K = M; p.a_rs = 1; p.a_ks = N; p.b_rs = 1; p.b_ks = K;
+  } else {
+    p.A = slab; p.B = W; p.bias = nullptr; p.C = part; p.pre = nullptr; p.rowsum = nullptr;
+    p.M = M; p.N = K; p.K = N; p.a_rs = N; p.a_ks = 1; p.b_rs = 1; p.b_ks = K;
+  }
+  p.act = 0;
+  gemm_tile<4>(p, vec_ok_dev(p.A, p.a_rs, p.a_ks), vec_ok_dev(p.B, p.b_rs, p.b_ks), bm.y, bm.z);
 }
 
 static bool vec_ok(const float* ptr, long rs, long ks) {
@@ -127,4 +170,19 @@ extern "C" int i2r_linear_bwd_f32(const float* x, const float* w, const float* d
     launch_gemm(p, (hipStream_t)stream);
   }
   return i2r_check_launch("linear_bwd");
+}
+
+// Grouped form over the network's `affine` layers; see gemm_grouped_kernel.  `emb` (M, K); `base` = the output slab
+// (mode 0) or the dy slab (modes 1, 2; mode 2 writes its partials behind it at the float offsets the blockmap carries).
+extern "C" int i2r_gemm_grouped_f32(const void* table, const void* blockmap, int nblocks, int mode, const float* emb,
+                                    float* base, int M, int K, i2r_stream_t stream) {
+  I2R_REQUIRE(table && blockmap && nblocks > 0 && emb && base && M > 0 && K > 0 && mode >= 0 && mode <= 2,
+              "gemm_grouped: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long* t = (const long*)table;
+  const int4* bmap = (const int4*)blockmap;
+  if (mode == 0) hipLaunchKernelGGL(gemm_grouped_kernel<0>, dim3(nblocks), dim3(256), 0, s, t, bmap, emb, base, M, K);
+  else if (mode == 1) hipLaunchKernelGGL(gemm_grouped_kernel<1>, dim3(nblocks), dim3(256), 0, s, t, bmap, emb, base, M, K);
+  else hipLaunchKernelGGL(gemm_grouped_kernel<2>, dim3(nblocks), dim3(256), 0, s, t, bmap, emb, base, M, K);
+  return i2r_check_launch("gemm_grouped");
 }

@@ -186,16 +186,18 @@ class UNetBlock(torch.nn.Module):
                               **(init_attn if init_attn is not None else init))
             self.proj = Conv2d(in_channels=out_channels, out_channels=out_channels, kernel=1, **init_zero)
 
-    def forward(self, x, emb):
+    def forward(self, x, emb, params=None):
         """networks.py:166-187 as 6 (+4 with attention) kernels:
         GN+SiLU -> conv0 -> affine -> GN+mod+SiLU(+dropout) -> [skip conv] -> conv1(+residual)
-        [-> GN -> qkv conv -> attention -> proj conv(+residual)]."""
+        [-> GN -> qkv conv -> attention -> proj conv(+residual)].
+        ``params``: this block's ``affine(emb)`` when the network computed all of them in one grouped launch."""
         orig = x
         # inference in f16x2 conv math: the norms hand the convs pre-split f16 pairs (no conversion in the conv)
         sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
         sp0 = sp and not (self.conv0.up or self.conv0.down)
         x = self.conv0(self.norm0(x, act_silu=True, split_out=sp0), x_split=sp0)
-        params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
+        if params is None:
+            params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
         x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0,
                        split_out=sp)
         skip = self.skip(orig) if self.skip is not None else orig
@@ -331,11 +333,33 @@ class DhariwalUNet(torch.nn.Module):
         emb = self.map_layer0(emb, act_silu=True)
         return self.map_layer1(emb, act_silu=True)
 
+    def affine_all(self, emb):
+        """``block.affine(emb)`` of every UNetBlock in one grouped launch (ops.AffineAllFn) -> {block: [scale|shift]}.
+        Used in inference, and in training when the affine parameters have gradient slots (FusedAdamW /
+        GradBucketReducer); otherwise None and each block runs its own Linear."""
+        blocks = [b for b in list(self.enc.values()) + list(self.dec.values()) if isinstance(b, UNetBlock)]
+        lins = [b.affine for b in blocks]
+        need_grad = torch.is_grad_enabled() and (emb.requires_grad or lins[0].weight.requires_grad)
+        if need_grad and any(getattr(l.weight, "_grad_slot", None) is None or
+                             getattr(l.bias, "_grad_slot", None) is None for l in lins):
+            return None
+        key = ops.AffinePlan.make_key(lins, emb.shape[0])
+        plan = getattr(self, "_affine_plan", None)
+        if plan is None or plan.key != key:
+            plan = self._affine_plan = ops.AffinePlan(lins, emb.shape[0])
+        flat = [t for l in lins for t in (l.weight, l.bias)]
+        outs = ops.AffineAllFn.apply(emb, plan, *flat)
+        if need_grad and outs[0].grad_fn is not None:
+            for o, slot in zip(outs, ops.AffineAllFn.dss_slots(outs[0].grad_fn.dys, plan)):
+                o._dss_slot = slot  # the consuming GroupNorm's backward writes d[scale|shift] here
+        return dict(zip(blocks, outs))
+
     def forward(self, x, noise_labels, class_labels=None, augment_labels=None):
         emb = self.embed(noise_labels)
+        ss = self.affine_all(emb)
         skips = []
         for block in self.enc.values():
-            x = block(x, emb) if isinstance(block, UNetBlock) else block(x)
+            x = block(x, emb, None if ss is None else ss[block]) if isinstance(block, UNetBlock) else block(x)
             skips.append(x)
         for block in self.dec.values():
             if x.shape[1] != block.in_channels:
@@ -344,7 +368,7 @@ class DhariwalUNet(torch.nn.Module):
                     x = (x, skip)  # norm0 and the 1x1 skip conv read the two tensors in place
                 else:
                     x = ops.ConcatFn.apply(x, skip)
-            x = block(x, emb)
+            x = block(x, emb, None if ss is None else ss[block])
         sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
         return self.out_conv(self.out_norm(x, act_silu=True, split_out=sp), x_split=sp)
 

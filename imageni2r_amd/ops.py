@@ -328,13 +328,22 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=Fa
 
 
 def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0, step=None,
-                  dgamma=None, dbeta=None):
+                  dgamma=None, dbeta=None, dss=None):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     _chk(dy, "dy")
     dx = torch.empty_like(x)
+    if ss is None:
+        dss = None
+    elif dss is None or tuple(dss.shape) != (B, 2 * C) or not dss.is_contiguous():
+        dss = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+    if dgamma is not None and dbeta is not None and slots_zeroed():
+        # the step's gradient slots were zero-filled: accumulate over the batch in place (no partials, no reduction)
+        _lib.call("i2r_groupnorm_bwd_acc_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0],
+                  _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dss), B, C, HW, groups,
+                  int(bool(act)), float(drop_p), int(seed), int(offset), _p(step), _stream())
+        return dx, dgamma, dbeta, dss
     part = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)  # per-sample [dgamma | dbeta]
-    dss = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device) if ss is not None else None
     _lib.call("i2r_groupnorm_bwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0], _p(mean),
               _p(rstd), _p(dy), _p(dx), _p(part), _p(dss), B, C, HW, groups, int(bool(act)),
               float(drop_p), int(seed), int(offset), _p(step), _stream())
@@ -583,6 +592,7 @@ class GroupNormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, ss, groups, eps, act, drop_p, seed, offset):
         x = _c(x)
         need_bwd = any(ctx.needs_input_grad[:4])
+        dss_slot = getattr(ss, "_dss_slot", None)  # AffineAllFn's dy slab piece for this layer, if grouped
         if ss is not None:
             ss = _c(ss)
         step = rng_step() if drop_p > 0.0 else None
@@ -591,6 +601,7 @@ class GroupNormFn(torch.autograd.Function):
             ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
             ctx.cfg = (groups, act, drop_p, seed, offset, step)
             ctx.slots = (getattr(gamma, "_grad_slot", None), getattr(beta, "_grad_slot", None))
+            ctx.dss_slot = dss_slot
         return y
 
     @staticmethod
@@ -602,7 +613,8 @@ class GroupNormFn(torch.autograd.Function):
         sg, sb = ctx.slots
         use = sg is not None and sb is not None
         dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset,
-                                        step, sg.detach() if use else None, sb.detach() if use else None)
+                                        step, sg.detach() if use else None, sb.detach() if use else None,
+                                        dss=ctx.dss_slot)
         return dx, dg, db, dss, None, None, None, None, None, None
 
 
@@ -646,6 +658,94 @@ class LinearFn(torch.autograd.Function):
                                 ctx.has_bias and ctx.needs_input_grad[2],
                                 dw=None if sw is None else sw.detach(), db=None if sb is None else sb.detach())
         return dx, dw, db, None
+
+
+class AffinePlan:
+    """Static launch tables of the grouped `affine` products for one set of Linear layers and one batch size M."""
+
+    def __init__(self, linears, M):
+        dev = linears[0].weight.device
+        K = linears[0].weight.shape[1]
+        self.M, self.K, self.L = M, K, len(linears)
+        self.N = [l.weight.shape[0] for l in linears]
+        self.off = [0]
+        for n in self.N:
+            self.off.append(self.off[-1] + M * n)
+        self.slab_floats = self.off[-1]
+        self.part_floats = self.L * M * K
+        rows = []
+        self.has_slots = all(getattr(l.weight, "_grad_slot", None) is not None and
+                             getattr(l.bias, "_grad_slot", None) is not None for l in linears)
+        for l, n, o in zip(linears, self.N, self.off):
+            dw = l.weight._grad_slot.data_ptr() if self.has_slots else 0
+            db = l.bias._grad_slot.data_ptr() if self.has_slots else 0
+            rows.append([l.weight.data_ptr(), l.bias.data_ptr(), dw, db, n, o])
+        self.slots = [(l.weight._grad_slot, l.bias._grad_slot) for l in linears] if self.has_slots else None
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        mt = (M + 31) // 32
+        fwd, dw_, dx = [], [], []
+        for i, n in enumerate(self.N):
+            fwd += [[i, bx, by, 0] for by in range(mt) for bx in range((n + 31) // 32)]
+            dw_ += [[i, bx, by, 0] for by in range((n + 31) // 32) for bx in range((K + 31) // 32)]
+            dx += [[i, bx, by, self.slab_floats + i * M * K] for by in range(mt) for bx in range((K + 31) // 32)]
+        self.maps = [torch.tensor(m, dtype=torch.int32).to(dev) for m in (fwd, dw_, dx)]
+        self.key = AffinePlan.make_key(linears, M)
+
+    @staticmethod
+    def make_key(linears, M):
+        return (M,) + tuple((l.weight.data_ptr(), l.bias.data_ptr(),
+                             getattr(l.weight, "_grad_slot", l.weight).data_ptr()) for l in linears)
+
+    def launch(self, mode, emb, base):
+        m = self.maps[mode]
+        _lib.call("i2r_gemm_grouped_f32", _p(self.table), _p(m), m.shape[0], mode, _p(emb), _p(base), self.M, self.K,
+                  _stream())
+
+
+class AffineAllFn(torch.autograd.Function):
+    """Every UNetBlock's ``affine(emb)`` (networks.py:170) at once: forward = one grouped launch into one slab whose
+    per-layer pieces are returned; backward = one launch for all dW/db (into the gradient slots), one for the per-layer
+    dx partials and one reduction.  The GroupNorm backward kernels write their d[scale|shift] straight into this
+    function's dy slab (``_dss_slot`` on each returned piece), so nothing is copied or accumulated per layer."""
+
+    @staticmethod
+    def forward(ctx, emb, plan, *params):
+        emb = _c(emb)
+        slab = torch.empty((plan.slab_floats,), dtype=torch.float32, device=emb.device)
+        plan.launch(0, emb, slab)
+        outs = tuple(slab[plan.off[i]: plan.off[i + 1]].view(plan.M, n) for i, n in enumerate(plan.N))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(emb)
+            ctx.plan = plan
+            # dy slab + room for the dx partials behind it; the GroupNorm backwards fill the pieces
+            ctx.dys = torch.empty((plan.slab_floats + plan.part_floats,), dtype=torch.float32, device=emb.device)
+        return outs
+
+    @staticmethod
+    def dss_slots(ctx_dys, plan):
+        return [ctx_dys[plan.off[i]: plan.off[i + 1]].view(plan.M, n) for i, n in enumerate(plan.N)]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (emb,) = ctx.saved_tensors
+        plan, dys = ctx.plan, ctx.dys
+        for i, (g, slot) in enumerate(zip(grads, AffineAllFn.dss_slots(dys, plan))):
+            if g is None:
+                slot.zero_()
+            elif g.data_ptr() != slot.data_ptr():
+                slot.copy_(g)
+        if not plan.has_slots:
+            raise _lib.I2RError("grouped affine backward needs gradient slots (FusedAdamW / GradBucketReducer)")
+        plan.launch(1, emb, dys)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            plan.launch(2, emb, dys)
+            part = dys[plan.slab_floats:].view(plan.L, plan.M * plan.K)
+            dx = reduce_rows(part).view(plan.M, plan.K)
+        out = [dx, None]
+        for sw, sb in plan.slots:  # aliases of the slots: autograd adopts them as .grad without a copy
+            out += [sw.detach(), sb.detach()]
+        return tuple(out)
 
 
 class EdmCombineFn(torch.autograd.Function):

@@ -112,6 +112,12 @@ int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta,
                           const float* mean, const float* rstd, const float* dy, float* dx, float* dgb_part,
                           float* dss, int B, int C, int HW, int G, int act, float drop_p, uint64_t seed,
                           uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
+/* same backward with dgamma / dbeta ADDED by fp32 atomics into caller-zeroed (C) buffers (the training step's
+ * gradient slots): no per-sample partials, no reduction launch; batch summation order is not fixed. */
+int i2r_groupnorm_bwd_acc_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
+                              const float* mean, const float* rstd, const float* dy, float* dx, float* dgamma_acc,
+                              float* dbeta_acc, float* dss, int B, int C, int HW, int G, int act, float drop_p,
+                              uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
 int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream);
 /* same with the columns split over two outputs: [0,cols_a) -> out_a, [cols_a, cols_a+cols_b) -> out_b */
 int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, int cols_a, int cols_b,
@@ -137,6 +143,13 @@ int i2r_linear_fwd_f32(const float* x, const float* w, const float* bias, float*
  * (db needs dw). */
 int i2r_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K,
                        int N, i2r_stream_t stream);
+/* Every `affine` Linear of the UNet (models/networks.py:170; all read the same embedding) in one launch per product.
+ * table: int64 rows {W, bias, dW, db, N, float offset of the layer in the slab}; blockmap: int32 {layer, tile x,
+ * tile y, partial offset}.  mode 0: y_l = emb W_l^T + b_l -> base + off_l;  mode 1: dW_l = dy_l^T emb, db_l = column
+ * sums (dy_l at base + off_l);  mode 2: partial dx_l = dy_l W_l -> base + blockmap.w (sum them with
+ * i2r_reduce_rows_f32).  emb is (M, K). */
+int i2r_gemm_grouped_f32(const void* table, const void* blockmap, int nblocks, int mode, const float* emb,
+                         float* base, int M, int K, i2r_stream_t stream);
 int i2r_silu_bwd_f32(const float* pre, const float* dy, float* dx, long n, i2r_stream_t stream);
 int i2r_add_f32(const float* a, const float* b, float* y, long n, i2r_stream_t stream);
 

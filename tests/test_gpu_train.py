@@ -264,3 +264,40 @@ def test_graphed_train_step_matches_eager():
     for a, b in zip(pe, pg):  # Adam's sign-like first steps amplify the last-bit noise of the atomics in wgrad
         assert rel_err(b.numpy(), a.numpy()) < 5e-3
     assert len(set(np.round(lg, 6))) > 1  # noise / sigma draws differ between replays
+
+
+def test_slot_path_gradients_vs_oracle():
+    """The training step's in-place gradient path -- gradient slots, grouped `affine` products (one launch for all
+    blocks, GroupNorm backwards writing d[scale|shift] into its slab), atomically accumulated GroupNorm dgamma/dbeta --
+    gives every parameter gradient of the golden loss within the path's 1e-4 bar of the oracle's autograd."""
+    from imageni2r_amd import FusedAdamW, TS2img_Karras, ops as _ops
+    from tests.helpers import load_golden
+    g = load_golden("g4_net.npz")
+    a = tiny_args()
+    torch.manual_seed(0)
+    m = TS2img_Karras(tiny_args(device=DEV), DEV)
+    O.perturb_zero_init(m.net.state_dict(), seed=1234)
+    m = m.to(DEV).eval()
+    spec = O.unet_spec(a.img_resolution, a.input_channels, a.unet_channels, a.ch_mult, a.attn_resolution)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.net.state_dict().items()
+          if not k.endswith("resample_filter")}
+    ref = O.masked_edm_loss(sd, spec, torch.from_numpy(g["loss_x_tilde"]), torch.from_numpy(g["loss_mask"]),
+                            torch.from_numpy(g["loss_rnd"]), torch.from_numpy(g["loss_noise"]))
+    ref.backward()
+    opt = FusedAdamW(m.net.parameters(), lr=1e-4, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    opt.bind_grads()
+    for rep in range(2):  # twice: the second pass must not see anything left over from the first
+        opt.zero_grad()
+        assert m.net.model.affine_all(torch.zeros(2, 4 * a.unet_channels, device=DEV, requires_grad=True)) is not None
+        _ops.set_slots_zeroed(True)
+        m.inject_randomness(cu(g["loss_rnd"]), cu(g["loss_noise"]))
+        try:
+            loss, _ = m.loss_fn_irregular(cu(g["loss_x_tilde"]), cu(g["loss_mask"]))
+            loss.backward()
+        finally:
+            m.inject_randomness(None, None)
+            _ops.set_slots_zeroed(False)
+        assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+        for k, p in m.net.named_parameters():
+            assert p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr(), k
+            assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-4, (rep, k)
