@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   const int j0 = blockIdx.x * BN;  // (ci, tap) tile
   const int kk = tid & 15, i0 = tid >> 4;
 
-  // per-thread constant decode of its EB im2col columns
-  int coff[EB], dr[EB], ds[EB];
+  // per-thread constants: its EB im2col columns (channel plane, tap shift) and its EA output-channel rows
+  int coff[EB], dr[EB], ds[EB], doff[EB];
   bool jok[EB];
 #pragma unroll
   for (int e = 0; e < EB; ++e) {
@@ -49,6 +49,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     coff[e] = ci * p.HW;
     dr[e] = (KS == 3) ? r - 1 : 0;
     ds[e] = (KS == 3) ? s - 1 : 0;
+    doff[e] = dr[e] * p.W + ds[e];
+  }
+  int arow[EA];
+  bool aok[EA];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) {
+    int co = m0 + i0 + 16 * e;
+    aok[e] = co < p.Cout;
+    arow[e] = aok[e] ? co * p.HW : 0;
   }
 
   f32x16 acc[TM][TN];
@@ -64,32 +73,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int e = 0; e < EA; ++e) bsum[e] = 0.0f;
   const bool want_bias = p.db != nullptr && blockIdx.x == 0;
-  auto load_chunk = [&](long nbase) {
-    long n = nbase + kk;
-    bool nv = n < p.Npos;
-    int b = 0, y = 0, x = 0, pos = 0;
-    if (nv) {
-      b = (int)(n / p.HW);
-      pos = (int)(n % p.HW);
-      y = pos / p.W;
-      x = pos % p.W;
-    }
-    const float* dyb = p.dy + (long)b * p.Cout * p.HW + pos;
-    const float* xb = p.x + (long)b * p.Cin * p.HW;
+  // Position of this thread's slot kk in the chunk being loaded, kept incrementally (one division per workgroup
+  // instead of four per chunk: the loader, not the MFMA, was the busiest unit of this kernel).
+  const long total_chunks = (p.Npos + BK - 1) / BK;
+  long c_begin = (long)blockIdx.z * p.chunks_per_split;
+  long c_end = c_begin + p.chunks_per_split;
+  if (c_end > total_chunks) c_end = total_chunks;
+  int pb, ppos;
+  {
+    long n = c_begin * BK + kk;
+    pb = (int)(n / p.HW);
+    ppos = (int)(n - (long)pb * p.HW);
+  }
+  const int wsh = (p.W & (p.W - 1)) == 0 ? __builtin_ctz(p.W) : -1;
+  auto load_chunk = [&]() {  // loads the chunk at (pb, ppos), then advances them by one chunk
+    const bool nv = pb < p.B;
+    const int y = wsh >= 0 ? (ppos >> wsh) : ppos / p.W;
+    const int x = ppos - y * p.W;
+    const float* dyb = p.dy + (long)pb * p.Cout * p.HW + ppos;
+    const float* xb = p.x + (long)pb * p.Cin * p.HW + ppos;
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
-      int co = m0 + i0 + 16 * e;
-      ra[e] = (nv && co < p.Cout) ? dyb[(long)co * p.HW] : 0.0f;
+      ra[e] = (nv && aok[e]) ? dyb[arow[e]] : 0.0f;
       bsum[e] += ra[e];
     }
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
       int iy = y + dr[e], ix = x + ds[e];
       float v = 0.0f;
-      if (nv && jok[e] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        v = xb[coff[e] + iy * p.W + ix];
+      if (nv && jok[e] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = xb[coff[e] + doff[e]];
       rb[e] = v;
     }
+    ppos += BK;
+    while (ppos >= p.HW) { ppos -= p.HW; ++pb; }
   };
   auto store_chunk = [&](int buf) {
     float* a = As + buf * BK * LDA;
@@ -100,17 +116,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     for (int e = 0; e < EB; ++e) b[kk * LDB + i0 + 16 * e] = rb[e];
   };
 
-  const long total_chunks = (p.Npos + BK - 1) / BK;
-  long c_begin = (long)blockIdx.z * p.chunks_per_split;
-  long c_end = c_begin + p.chunks_per_split;
-  if (c_end > total_chunks) c_end = total_chunks;
   if (c_begin < c_end) {
-    load_chunk(c_begin * BK);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     for (long c = c_begin; c < c_end; ++c) {
       int cur = (int)((c - c_begin) & 1);
-      if (c + 1 < c_end) load_chunk((c + 1) * BK);
+      if (c + 1 < c_end) load_chunk();
       mma_chunk<WM, WN, TM, TN, BK>(As + cur * BK * LDA, Bs + cur * BK * LDB, LDA, LDB, acc, wm, wn, l31, h);
       if (c + 1 < c_end) store_chunk(cur ^ 1);
       __syncthreads();
