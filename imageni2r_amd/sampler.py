@@ -43,6 +43,8 @@ class DiffusionProcess:
         self.num_steps = args.diffusion_steps
         self.use_graph = use_graph
         self._graphs = {}
+        self.dual_stream_min = 2048  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
+        self._streams = None
 
     # ------------------------------------------------------------------------------------------------------
     def _t_steps(self):
@@ -69,6 +71,28 @@ class DiffusionProcess:
                 x_cur, x_next = x_next, x_cur
         return x_cur
 
+    def _graph_entry(self, latents, t_steps, t_host, slot=0):
+        """(graph, static_in, static_out, sigma table) for this batch shape, captured on first use."""
+        key = self._graph_key(latents) + (slot,)
+        entry = self._graphs.get(key)
+        if entry is None:
+            sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
+            static_in = latents.clone()
+            # one eager pass on a side stream warms allocator + library state before capture
+            side = torch.cuda.Stream(device=latents.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._loop(static_in, t_host, sig_dev)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ops.new_pack_epoch()  # weights are re-packed INSIDE the graph: replays always see live weights
+                static_out = self._loop(static_in, t_host, sig_dev)
+            ops.new_pack_epoch()      # and eager code never reuses the graph-owned packed buffers
+            entry = (graph, static_in, static_out, sig_dev)
+            self._graphs[key] = entry
+        return entry
+
     def _graph_key(self, latents):
         return (tuple(latents.shape), latents.device.index,
                 hash(tuple(p.data_ptr() for p in self.net.parameters())))
@@ -88,25 +112,24 @@ class DiffusionProcess:
             if not self.use_graph:
                 sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
                 return self._loop(latents, t_host, sig_dev)
-            key = self._graph_key(latents)
-            entry = self._graphs.get(key)
-            if entry is None:
-                sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
-                static_in = latents.clone()
-                # one eager pass on a side stream warms allocator + library state before capture
-                side = torch.cuda.Stream(device=latents.device)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self._loop(static_in, t_host, sig_dev)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    ops.new_pack_epoch()  # weights are re-packed INSIDE the graph: replays always see live weights
-                    static_out = self._loop(static_in, t_host, sig_dev)
-                ops.new_pack_epoch()      # and eager code never reuses the graph-owned packed buffers
-                entry = (graph, static_in, static_out, sig_dev)
-                self._graphs[key] = entry
-            graph, static_in, static_out, _ = entry
+            n = latents.shape[0]
+            if self.dual_stream_min and n >= self.dual_stream_min and n % 2 == 0:
+                # Two half-batch graphs replayed side by side on two streams: the HBM-bound kernels of one half
+                # (GroupNorm, 1x1 convs) run beside the matrix-core-bound 3x3 convs of the other (+2-3 % series/s).
+                parts = latents.chunk(2)
+                entries = [self._graph_entry(p, t_steps, t_host, slot=i) for i, p in enumerate(parts)]
+                if self._streams is None:
+                    self._streams = [torch.cuda.Stream(device=latents.device) for _ in range(2)]
+                cur = torch.cuda.current_stream()
+                for st, (graph, static_in, _, _), p in zip(self._streams, entries, parts):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        static_in.copy_(p)
+                        graph.replay()
+                for st in self._streams:
+                    cur.wait_stream(st)
+                return torch.cat([e[2] for e in entries])
+            graph, static_in, static_out, _ = self._graph_entry(latents, t_steps, t_host)
             static_in.copy_(latents)
             graph.replay()
             return static_out.clone()

@@ -423,6 +423,26 @@ def test_sampler_golden(tiny_gpu):
     assert rel_err(ts.cpu().numpy(), ref_ts) < TOL
 
 
+def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
+    """Large batches are sampled as two half-batch graphs replayed side by side on two streams: same series as one
+    graph over the whole batch (per-series arithmetic does not depend on the batch), and stable across replays."""
+    from imageni2r_amd import DiffusionProcess
+    args = tiny_args(device=DEV)
+    xT = torch.randn(8, 3, 8, 8, generator=torch.Generator().manual_seed(5))
+    one = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8))
+    one.dual_stream_min = 0
+    ref = one.sample(xT)
+    two = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8))
+    two.dual_stream_min = 4
+    out = two.sample(xT)
+    assert len(two._graphs) == 2 and tuple(out.shape) == (8, 3, 8, 8)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert torch.equal(out, two.sample(xT))
+    g = load_golden("g5_sampler.npz")  # and the golden pair still comes out right through the split path
+    two.dual_stream_min = 2
+    assert rel_err(two.sample(torch.from_numpy(g["xT"])).cpu().numpy(), g["out"]) < TOL
+
+
 def test_training_step_with_dropout_runs(tiny_gpu):
     """train() mode: dropout live, in-kernel Philox noise; loss finite, every parameter gets a finite gradient."""
     m = tiny_gpu
