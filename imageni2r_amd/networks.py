@@ -100,9 +100,10 @@ class Conv2d(torch.nn.Module):
             return self._wpd
         return None
 
-    def forward(self, x, residual=None, x_split=False):
+    def forward(self, x, residual=None, x_split=False, out=None):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue.  ``x_split``: x is the
-        pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only)."""
+        pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only).
+        ``out`` (inference f16x2 path only): destination tensor."""
         if x_split and (self.up or self.down or torch.is_grad_enabled() or ops.conv_math() != "f16x2"):
             raise ValueError("x_split is only valid for a plain inference conv in f16x2 mode")
         if isinstance(x, tuple):  # (x, skip): torch.cat([x, skip], 1) read in place -- inference 1x1 convs only
@@ -115,7 +116,7 @@ class Conv2d(torch.nn.Module):
         if self.weight is not None:
             if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
-                                         None if residual is None else ops._c(residual), x_split)
+                                         None if residual is None else ops._c(residual), x_split, out)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -203,10 +204,30 @@ class UNetBlock(torch.nn.Module):
         skip = self.skip(orig) if self.skip is not None else orig
         x = self.conv1(x, residual=skip, x_split=sp)
         if self.num_heads:
+            chunk = self._attn_chunk(x) if sp else 0
+            if chunk:
+                # inference at large batch: the attention tail runs over sample chunks whose qkv / attention tensors
+                # (3C and C channels) stay in the 256 MB infinity cache between the four kernels
+                out = torch.empty_like(x)
+                for i in range(0, x.shape[0], chunk):
+                    xc = x[i:i + chunk]
+                    qkv = self.qkv(self.norm2(xc, split_out=True), x_split=True)
+                    a = ops.AttentionFn.apply(qkv, self.num_heads)
+                    self.proj(a, residual=xc, out=out[i:i + chunk])
+                return out
             qkv = self.qkv(self.norm2(x, split_out=sp), x_split=sp)
             a = ops.AttentionFn.apply(qkv, self.num_heads)
             x = self.proj(a, residual=x)
         return x
+
+    ATTN_CHUNK_BYTES = 256e6  # qkv bytes per chunk of the chunked attention tail (0 disables chunking)
+
+    def _attn_chunk(self, x):
+        per_sample = 3 * x.shape[1] * x.shape[2] * x.shape[3] * 4
+        if not self.ATTN_CHUNK_BYTES:
+            return 0
+        chunk = 1 << max(0, int(self.ATTN_CHUNK_BYTES // per_sample).bit_length() - 1)
+        return chunk if x.shape[0] >= 2 * chunk else 0
 
 
 class PositionalEmbedding(torch.nn.Module):

@@ -194,15 +194,18 @@ def conv2d_pack_h2(w):
     return wp
 
 
-def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False):
+def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None):
     """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip).  ``x_split``: x holds
-    pre-split f16 pairs (groupnorm_fwd(..., split_out=True))."""
+    pre-split f16 pairs (groupnorm_fwd(..., split_out=True)).  ``out``: write into this (B, Cout, H, W) tensor."""
     _chk(x, "x")
     Cout, Cin, k, _ = w_shape
     B, Cin2, H, W = x.shape
     if Cin2 != Cin:
         raise ValueError("conv2d_fwd_h2: channel mismatch")
-    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(_chk(out, "out").shape) != (B, Cout, H, W):
+        raise ValueError("conv2d_fwd_h2: out has the wrong shape")
     if residual is not None:
         _chk(residual, "residual")
     nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
