@@ -161,7 +161,22 @@ __device__ __forceinline__ void a_split8(const float* v, ah8& hi, ah8& lo) {
 #define AKROW 144  // bytes per key row of the K image: 64 d x 2 B + 16 pad (odd multiple of 16 B)
 #define AVROW 80   // bytes per channel row of the V image: 32 keys x 2 B + 16 pad
 
-template <int QW>
+// words that already hold f16 hi | f16 lo << 16 (written by the qkv conv's epilogue): fragments by byte permutes only
+__device__ __forceinline__ void a_unpack8(const float* v, ah8& hi, ah8& lo) {
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned w0 = __builtin_bit_cast(unsigned, v[2 * i]), w1 = __builtin_bit_cast(unsigned, v[2 * i + 1]);
+    hw[i] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    lw[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+  }
+  au4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+  hi = __builtin_bit_cast(ah8, hv);
+  lo = __builtin_bit_cast(ah8, lv);
+}
+
+// PRE: qkv arrives pre-split (and q pre-scaled) from i2r_conv2d_fwd_h2's qkv output mode.
+template <int QW, bool PRE>
 __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int heads, int T) {
   constexpr int NT = 64 * QW, NIT = 256 / NT;                 // staging work items per thread
@@ -180,8 +195,12 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
   for (int s = 0; s < 4; ++s) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = base[(long)(3 * (16 * s + 8 * h + j) + 0) * T + q0 + l31] * 0.18033688011112042f;
-    a_split8(v, qh[s], ql[s]);
+    for (int j = 0; j < 8; ++j) {
+      v[j] = base[(long)(3 * (16 * s + 8 * h + j) + 0) * T + q0 + l31];
+      if (!PRE) v[j] *= I2R_QSCALE;
+    }
+    if (PRE) a_unpack8(v, qh[s], ql[s]);
+    else a_split8(v, qh[s], ql[s]);
   }
 
   f32x16 O[2];
@@ -214,13 +233,15 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
       int item = tid + NT * it;
       int key = item & 31, dg = item >> 5;
       ah8 hi, lo;
-      a_split8(kreg[it], hi, lo);
+      if (PRE) a_unpack8(kreg[it], hi, lo);
+      else a_split8(kreg[it], hi, lo);
       *reinterpret_cast<ah8*>(st + key * AKROW + dg * 16) = hi;
       *reinterpret_cast<ah8*>(st + KBYTES + key * AKROW + dg * 16) = lo;
       int c = item >> 2, piece = item & 3;
       float vv[8] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w,
                      vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
-      a_split8(vv, hi, lo);
+      if (PRE) a_unpack8(vv, hi, lo);
+      else a_split8(vv, hi, lo);
       *reinterpret_cast<ah8*>(st + 2 * KBYTES + c * AVROW + piece * 16) = hi;
       *reinterpret_cast<ah8*>(st + 2 * KBYTES + VBYTES + c * AVROW + piece * 16) = lo;
     }
@@ -296,16 +317,19 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
 }
 
 // f16x2-split inference forward; T must be a multiple of 32 and > 32 (smaller T: i2r_attention_fwd_f32's LDS kernel).
-extern "C" int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, i2r_stream_t stream) {
+// presplit: qkv was written by i2r_conv2d_fwd_h2 with flag bit 1 (split pairs, q pre-scaled).
+extern "C" int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, int presplit,
+                                    i2r_stream_t stream) {
   I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 32 && T % 32 == 0, "attention_fwd_h2: bad argument (T=%d)", T);
   I2R_REQUIRE((((uintptr_t)qkv) & 15) == 0, "attention_fwd_h2: qkv must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (T % 128 == 0)
-    hipLaunchKernelGGL(attn_fwd_h2_kernel<4>, dim3(T / 128, B * heads), dim3(256), 0, s, qkv, out, heads, T);
-  else if (T % 64 == 0)
-    hipLaunchKernelGGL(attn_fwd_h2_kernel<2>, dim3(T / 64, B * heads), dim3(128), 0, s, qkv, out, heads, T);
-  else
-    hipLaunchKernelGGL(attn_fwd_h2_kernel<1>, dim3(T / 32, B * heads), dim3(64), 0, s, qkv, out, heads, T);
+#define ATT_GO(QW_, PRE_)                                                                                          \
+  hipLaunchKernelGGL((attn_fwd_h2_kernel<QW_, PRE_>), dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 0, s, qkv, out, \
+                     heads, T)
+  if (T % 128 == 0) { if (presplit) ATT_GO(4, true); else ATT_GO(4, false); }
+  else if (T % 64 == 0) { if (presplit) ATT_GO(2, true); else ATT_GO(2, false); }
+  else { if (presplit) ATT_GO(1, true); else ATT_GO(1, false); }
+#undef ATT_GO
   return i2r_check_launch("attention_fwd_h2");
 }
 

@@ -41,6 +41,8 @@ struct ConvHParams {
   int chunks_per_split, nsplit, mtiles;
   long slab_stride;
   int ablate;  // tuning only (I2R_H2_ABLATE): 1 = skip the epilogue stores, 2 = skip the main loop
+  int qkv_out; // 1: the output feeds i2r_attention_fwd_h2(presplit): q channels (c % 3 == 0) are scaled by I2R_QSCALE and
+               // every element is stored as the split pair f16 hi | f16 lo << 16 (the attention kernel then only permutes)
 };
 
 __device__ __forceinline__ float bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -90,6 +92,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
   const unsigned voff = nvalid ? ((pb * (unsigned)p.Cout + (unsigned)(m0 + 4 * h)) * (unsigned)p.HW + pos) * 4u : OOR;
   const int lim = p.Cout - m0 - 4 * h;  // channel offsets below lim exist
   const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
+  const int cmod = (m0 + 4 * h) % 3;  // (head, d, {q,k,v}) interleave: channel % 3 == 0 is a q row
   float bv[4][16], rv[4][16];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -106,6 +109,10 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
     for (int r = 0; r < 16; ++r) {
       const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
       float v = acc[t][r] * WSCALE_INV + bv[t][r] + rv[t][r];
+      if (p.qkv_out) {
+        if ((cmod + cof) % 3 == 0) v *= I2R_QSCALE;
+        v = split_pack(v);
+      }
       unsigned vo = (cof < lim && (!(ablate & 1) || v == 12345.678f)) ? voff : OOR;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, vo, (unsigned)cof * plane, 0);
     }
@@ -484,7 +491,10 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
               "buffer-addressing limit; split the batch", x_bytes, out_bytes, wp_bytes);
   long Npos = (long)B * H * W;
   int chunks = h2_chunks(Cin, ksize), bn, nsplit, cps;
-  h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr, bn, nsplit, cps);
+  const int qkv_out = (x_is_split >> 1) & 1;  // flag bit 1: split-pair qkv output for the attention kernel
+  x_is_split &= 1;
+  I2R_REQUIRE(!qkv_out || Cout % 3 == 0, "conv2d_fwd_h2: qkv output needs Cout %% 3 == 0 (got %d)", Cout);
+  h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr && !qkv_out, bn, nsplit, cps);  // split-K partials are fp32
   if (nsplit > 1 && (long)nsplit * Npos * Cout > splitk_floats) { nsplit = 1; cps = chunks; }
   ConvHParams p;
   p.x = x; p.x2 = x2; p.wp = wp; p.bias = bias; p.res = residual;
@@ -493,6 +503,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.B = B; p.Cin = Cin; p.Cin1 = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.HW = H * W; p.nCB = h2_ncb(Cin, ksize);
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  p.qkv_out = qkv_out;
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);
   dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);

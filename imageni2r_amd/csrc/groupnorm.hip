@@ -24,14 +24,6 @@ __device__ __forceinline__ uint64_t eff_offset(uint64_t offset, const uint64_t* 
   return rng_step ? offset + (rng_step[0] << 20) : offset;
 }
 
-// y -> f16 hi | f16 lo << 16 (the operand format of the split-f16 inference conv), carried in a float register
-__device__ __forceinline__ float split_pack(float y) {
-  _Float16 hi, lo;
-  f16_split(y, hi, lo);
-  unsigned w = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-  return __builtin_bit_cast(float, w);
-}
-
 template <int LPG>
 __device__ __forceinline__ float seg_sum(float v) {
 #pragma unroll

@@ -66,6 +66,16 @@ __device__ __forceinline__ void f16_split(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(x - (float)hi);
 }
 
+// y -> f16 hi | f16 lo << 16: the pre-split operand word of the f16x2 kernels, carried in a float register
+__device__ __forceinline__ float split_pack(float y) {
+  _Float16 hi, lo;
+  f16_split(y, hi, lo);
+  unsigned w = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+  return __builtin_bit_cast(float, w);
+}
+// softmax scale of the attention logits folded into q: 1/sqrt(64) * log2(e)  (the kernels run the softmax on exp2)
+#define I2R_QSCALE 0.18033688011112042f
+
 // Philox4x32-10 counter RNG (used for dropout keep-masks and training noise; regenerated, never stored)
 __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import itertools
 
+import os
+
 import numpy as np
 import torch
 
@@ -100,7 +102,7 @@ class Conv2d(torch.nn.Module):
             return self._wpd
         return None
 
-    def forward(self, x, residual=None, x_split=False, out=None):
+    def forward(self, x, residual=None, x_split=False, out=None, qkv_out=False):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue.  ``x_split``: x is the
         pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only).
         ``out`` (inference f16x2 path only): destination tensor."""
@@ -116,7 +118,7 @@ class Conv2d(torch.nn.Module):
         if self.weight is not None:
             if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
-                                         None if residual is None else ops._c(residual), x_split, out)
+                                         None if residual is None else ops._c(residual), x_split, out, qkv_out)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -211,14 +213,19 @@ class UNetBlock(torch.nn.Module):
                 out = torch.empty_like(x)
                 for i in range(0, x.shape[0], chunk):
                     xc = x[i:i + chunk]
-                    qkv = self.qkv(self.norm2(xc, split_out=True), x_split=True)
-                    a = ops.AttentionFn.apply(qkv, self.num_heads)
-                    self.proj(a, residual=xc, out=out[i:i + chunk])
+                    self.proj(self._attend(xc, True), residual=xc, out=out[i:i + chunk])
                 return out
-            qkv = self.qkv(self.norm2(x, split_out=sp), x_split=sp)
-            a = ops.AttentionFn.apply(qkv, self.num_heads)
-            x = self.proj(a, residual=x)
+            x = self.proj(self._attend(x, sp), residual=x)
         return x
+
+    def _attend(self, x, sp):
+        """norm2 -> qkv conv -> attention.  In f16x2 inference the qkv conv writes split pairs (q pre-scaled) and the
+        attention kernel only permutes them into fragments."""
+        if sp:
+            pre = ops.attention_h2_ok(x.shape[2] * x.shape[3]) and not os.environ.get("I2R_NO_QKV_PRESPLIT")
+            qkv = self.qkv(self.norm2(x, split_out=True), x_split=True, qkv_out=pre)
+            return ops.attention_fwd(qkv, self.num_heads, presplit=pre)[0]
+        return ops.AttentionFn.apply(self.qkv(self.norm2(x)), self.num_heads)
 
     ATTN_CHUNK_BYTES = 256e6  # qkv bytes per chunk of the chunked attention tail (0 disables chunking)
 

@@ -194,9 +194,10 @@ def conv2d_pack_h2(w):
     return wp
 
 
-def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None):
+def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None, qkv_out=False):
     """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip).  ``x_split``: x holds
-    pre-split f16 pairs (groupnorm_fwd(..., split_out=True)).  ``out``: write into this (B, Cout, H, W) tensor."""
+    pre-split f16 pairs (groupnorm_fwd(..., split_out=True)).  ``out``: write into this (B, Cout, H, W) tensor.
+    ``qkv_out``: store the result as split pairs with the q rows pre-scaled, for attention_fwd(presplit=True)."""
     _chk(x, "x")
     Cout, Cin, k, _ = w_shape
     B, Cin2, H, W = x.shape
@@ -211,7 +212,7 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=N
     nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
     ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
     _lib.call("i2r_conv2d_fwd_h2", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W, Cout, k,
-              int(bool(x_split)), _stream())
+              int(bool(x_split)) | (2 if qkv_out else 0), _stream())
     return out
 
 
@@ -358,7 +359,12 @@ def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, s
     return dx, dgb[:C], dgb[C:], dss
 
 
-def attention_fwd(qkv, heads, save_lse=False):
+def attention_h2_ok(T) -> bool:
+    """Shapes the f16x2 inference attention kernel covers (others take the fp32 kernels)."""
+    return conv_math() == "f16x2" and T > 32 and T % 32 == 0
+
+
+def attention_fwd(qkv, heads, save_lse=False, presplit=False):
     _chk(qkv, "qkv")
     B, C3 = qkv.shape[0], qkv.shape[1]
     C = C3 // 3
@@ -366,9 +372,11 @@ def attention_fwd(qkv, heads, save_lse=False):
         raise ValueError(f"attention: channels {C} != heads*64 ({heads}*64); head dim is fixed at 64")
     T = qkv.numel() // (B * C3)
     out = torch.empty((B, C) + tuple(qkv.shape[2:]), dtype=torch.float32, device=qkv.device)
-    if not save_lse and conv_math() == "f16x2" and T > 32 and T % 32 == 0:
-        _lib.call("i2r_attention_fwd_h2", _p(qkv), _p(out), B, heads, T, _stream())  # inference: f16x2-split MFMA
-        return out, None
+    if not save_lse and attention_h2_ok(T):
+        _lib.call("i2r_attention_fwd_h2", _p(qkv), _p(out), B, heads, T, int(bool(presplit)), _stream())
+        return out, None  # inference: f16x2-split MFMA
+    if presplit:
+        raise ValueError("attention_fwd: presplit qkv is only understood by the f16x2 inference kernel")
     lse = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device) if save_lse else None
     _lib.call("i2r_attention_fwd_f32", _p(qkv), _p(out), _p(lse), B, heads, T, _stream())
     return out, lse

@@ -69,8 +69,10 @@ int i2r_conv2d_dgrad_f32(const float* dy, const float* w, float* ws, long ws_flo
 long i2r_conv2d_packed_h2_bytes(int Cout, int Cin, int ksize);
 int i2r_conv2d_pack_weight_h2(const float* w /* OIHW */, void* wp, int Cout, int Cin, int ksize, i2r_stream_t stream);
 long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksize);
-/* x_is_split: the activations were already split by their producer (i2r_groupnorm_fwd_f32 with split_out): each 32-bit
- * element holds f16 hi | f16 lo << 16 in the same NCHW positions. */
+/* x_is_split is a flag word.  Bit 0: the activations were already split by their producer (i2r_groupnorm_fwd_f32 with
+ * split_out): each 32-bit element holds f16 hi | f16 lo << 16 in the same NCHW positions.  Bit 1: the OUTPUT is the qkv
+ * tensor of an attention block and is stored in that split form, q rows (channel % 3 == 0) pre-multiplied by the softmax
+ * scale, for i2r_attention_fwd_h2 with presplit = 1; needs Cout % 3 == 0, and split-K is not used for it. */
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       int x_is_split, i2r_stream_t stream);
@@ -127,8 +129,9 @@ int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, 
 /* qkv (B, 3*heads*64, T) interleaved (head, d, {q,k,v}); out (B, heads*64, T); lse (B*heads*T) optional (backward). */
 int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T, i2r_stream_t stream);
 /* inference forward of the same op on the f16 matrix cores with fp32-grade accuracy (f16x2 split, see
- * i2r_conv2d_fwd_h2); T a multiple of 32 and > 32; qkv 16-byte aligned. */
-int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, i2r_stream_t stream);
+ * i2r_conv2d_fwd_h2); T a multiple of 32 and > 32; qkv 16-byte aligned.  presplit: qkv holds split pairs with q
+ * pre-scaled (i2r_conv2d_fwd_h2 flag bit 1) -- the kernel then converts nothing. */
+int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, int presplit, i2r_stream_t stream);
 /* AttentionOp.backward (:121-126) + einsum backward: dqkv (B,3C,T); delta_ws: workspace of B*heads*T floats. */
 int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                           float* delta_ws, int B, int heads, int T, i2r_stream_t stream);

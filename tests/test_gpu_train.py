@@ -137,11 +137,31 @@ def test_attention_split_f16_vs_oracle(ops, B, heads, H):
     q = cu(qkv.numpy())
     out = torch.empty(B, C, H, H, device=DEV)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.call("i2r_attention_fwd_h2", vp(q), vp(out), B, heads, H * H,
+    _lib.call("i2r_attention_fwd_h2", vp(q), vp(out), B, heads, H * H, 0,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 5e-6
     a, _ = ops.attention_fwd(q, heads)  # the dispatcher picks the same kernel in f16x2 mode
     assert torch.equal(a, out)
+
+
+@pytest.mark.parametrize("B,C,H", [(3, 128, 16), (2, 256, 8), (1, 128, 32)])
+def test_qkv_conv_split_output_feeds_presplit_attention(ops, B, C, H):
+    """The qkv 1x1 conv storing split pairs (q rows pre-scaled) + the attention kernel that only permutes them:
+    the pair matches the fp64 composition, and the separate (fp32 qkv) route, to fp32-grade accuracy."""
+    heads = C // 64
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, H, generator=gen)
+    w = torch.randn(3 * C, C, 1, 1, generator=gen) / np.sqrt(C) * 1.5
+    b = torch.randn(3 * C, generator=gen) * 0.5
+    qkv_ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    ref = O.attention(qkv_ref, heads)
+    wp = ops.conv2d_pack_h2(cu(w.numpy()))
+    xd, bd = cu(x.numpy()), cu(b.numpy())
+    qkv_sp = ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, bd, None, qkv_out=True)
+    a_sp, _ = ops.attention_fwd(qkv_sp, heads, presplit=True)
+    assert rel_err(a_sp.cpu().numpy(), ref.numpy()) < 5e-6
+    a_plain, _ = ops.attention_fwd(ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, bd, None), heads)
+    assert rel_err(a_sp.cpu().numpy(), a_plain.cpu().numpy()) < 5e-6
 
 
 @pytest.mark.parametrize("B,C1,C2,H,Cout", [(3, 256, 128, 8, 256), (2, 512, 512, 2, 512), (2, 256, 256, 4, 256),
