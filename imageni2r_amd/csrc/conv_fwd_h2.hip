@@ -41,6 +41,8 @@ struct ConvHParams {
   int chunks_per_split, nsplit, mtiles;
   long slab_stride;
   int ablate;  // tuning only (I2R_H2_ABLATE): 1 = skip the epilogue stores, 2 = skip the main loop
+  int up_in;   // 1 (3x3 DPP path): x is (B, Cin, H/2, W/2) and is nearest-upsampled x2 on the fly (Conv2d up=True, :79-81)
+  int up_res;  // 1: the residual is (B, Cout, H/2, W/2), nearest-upsampled x2 on the fly (the kernel-0 `skip` of up blocks)
   int qkv_out; // 1: the output feeds i2r_attention_fwd_h2(presplit): q channels (c % 3 == 0) are scaled by I2R_QSCALE and
                // every element is stored as the split pair f16 hi | f16 lo << 16 (the attention kernel then only permutes)
 };
@@ -87,9 +89,18 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
                                             bool nvalid, unsigned pb, unsigned pos, int m0, int h, int ablate) {
   const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
   __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)out_bytes, 0x00020000);
   const unsigned plane = (unsigned)p.HW * 4;
   const unsigned voff = nvalid ? ((pb * (unsigned)p.Cout + (unsigned)(m0 + 4 * h)) * (unsigned)p.HW + pos) * 4u : OOR;
+  // residual: same element, or (up_res) its nearest-x2 source in a half-resolution tensor
+  unsigned rplane = plane, rvoff = voff, res_bytes = out_bytes;
+  if (p.up_res) {
+    const unsigned y = pos / (unsigned)p.W, x = pos - y * (unsigned)p.W, hwl = (unsigned)p.HW >> 2;
+    rplane = hwl * 4;
+    res_bytes = out_bytes >> 2;
+    rvoff = nvalid ? ((pb * (unsigned)p.Cout + (unsigned)(m0 + 4 * h)) * hwl + (y >> 1) * ((unsigned)p.W >> 1) + (x >> 1)) * 4u
+                   : OOR;
+  }
+  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)res_bytes, 0x00020000);
   const int lim = p.Cout - m0 - 4 * h;  // channel offsets below lim exist
   const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
   const int cmod = (m0 + 4 * h) % 3;  // (head, d, {q,k,v}) interleave: channel % 3 == 0 is a q row
@@ -101,7 +112,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
       const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
       const bool ok = cof < lim;
       bv[t][r] = (use_bias && ok) ? p.bias[m0 + 4 * h + cof] : 0.0f;
-      rv[t][r] = use_res ? bufload(rR, ok ? voff : OOR, (unsigned)cof * plane) : 0.0f;
+      rv[t][r] = use_res ? bufload(rR, ok ? rvoff : OOR, (unsigned)cof * rplane) : 0.0f;
     }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -189,12 +200,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
     px = pos % p.W;
   }
   const bool has_left = px > 0, has_right = px < p.W - 1;
-  const unsigned chan_bytes = (unsigned)p.HW * 4;
+  const int us = p.up_in;  // 0 / 1: source rows, columns and planes are halved when the input is upsampled on the fly
+  const unsigned chan_bytes = (unsigned)(p.HW >> (2 * us)) * 4;
   unsigned voffB[3];
   auto set_row = [&](int r) {  // voffsets of the tap columns of kernel row r for this lane's position
     int iy = py + r - 1;
     bool rok = nvalid && (unsigned)iy < (unsigned)p.H;
     long off = ((long)pb * p.Cin + 8 * h) * p.HW + iy * p.W + px;
+    if (DPP && us)  // nearest x2: tap (iy, px) of the upsampled image is source pixel (iy >> 1, px >> 1); the DPP
+                    // neighbours (px -+ 1) then hold exactly the left / right taps of the upsampled row
+      off = ((long)pb * p.Cin + 8 * h) * (p.HW >> 2) + (iy >> 1) * (p.W >> 1) + (px >> 1);
     if (DPP) {
       voffB[0] = rok ? (unsigned)(off * 4) : OOR;
     } else {
@@ -492,9 +507,17 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   long Npos = (long)B * H * W;
   int chunks = h2_chunks(Cin, ksize), bn, nsplit, cps;
   const int qkv_out = (x_is_split >> 1) & 1;  // flag bit 1: split-pair qkv output for the attention kernel
+  const int up_in = (x_is_split >> 2) & 1;    // flag bit 2: x is half resolution, upsampled x2 on the fly
+  const int up_res = (x_is_split >> 3) & 1;   // flag bit 3: residual is half resolution, upsampled x2 on the fly
   x_is_split &= 1;
+  I2R_REQUIRE(!(up_in || up_res) || (H % 2 == 0 && W % 2 == 0), "conv2d_fwd_h2: x2 upsampling needs even H, W");
+  I2R_REQUIRE(!up_in || (ksize == 3 && !x2 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP")),
+              "conv2d_fwd_h2: fused upsampling is built for the 3x3 DPP path only (W a power of two <= 32)");
+  I2R_REQUIRE(!up_res || residual, "conv2d_fwd_h2: up_res without a residual");
+  if (up_in) x_bytes /= 4;
   I2R_REQUIRE(!qkv_out || Cout % 3 == 0, "conv2d_fwd_h2: qkv output needs Cout %% 3 == 0 (got %d)", Cout);
-  h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr && !qkv_out, bn, nsplit, cps);  // split-K partials are fp32
+  // split-K partials are fp32 and its reduce kernel adds a full-resolution residual: not for qkv_out / up_res
+  h2_plan(Npos, Cout, ksize, chunks, splitk_ws != nullptr && !qkv_out && !up_res, bn, nsplit, cps);
   if (nsplit > 1 && (long)nsplit * Npos * Cout > splitk_floats) { nsplit = 1; cps = chunks; }
   ConvHParams p;
   p.x = x; p.x2 = x2; p.wp = wp; p.bias = bias; p.res = residual;
@@ -503,7 +526,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.B = B; p.Cin = Cin; p.Cin1 = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.HW = H * W; p.nCB = h2_ncb(Cin, ksize);
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-  p.qkv_out = qkv_out;
+  p.qkv_out = qkv_out; p.up_in = up_in; p.up_res = up_res;
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);
   dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);

@@ -102,12 +102,18 @@ class Conv2d(torch.nn.Module):
             return self._wpd
         return None
 
-    def forward(self, x, residual=None, x_split=False, out=None, qkv_out=False):
+    def forward(self, x, residual=None, x_split=False, out=None, qkv_out=False, fuse_up=False, up_res=False):
         """up/down resample, conv, + bias (:68-90); ``residual`` is added in the conv epilogue.  ``x_split``: x is the
         pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only).
         ``out`` (inference f16x2 path only): destination tensor."""
-        if x_split and (self.up or self.down or torch.is_grad_enabled() or ops.conv_math() != "f16x2"):
+        if x_split and ((self.up and not fuse_up) or self.down or torch.is_grad_enabled()
+                        or ops.conv_math() != "f16x2"):
             raise ValueError("x_split is only valid for a plain inference conv in f16x2 mode")
+        if fuse_up:  # inference f16x2, 3x3: the nearest x2 upsample (:79-81) happens in the conv's own addressing
+            if not self.up or torch.is_grad_enabled() or ops.conv_math() != "f16x2":
+                raise ValueError("fuse_up needs an up=True conv in f16x2 inference")
+            return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
+                                     None if residual is None else ops._c(residual), x_split, out, False, True, up_res)
         if isinstance(x, tuple):  # (x, skip): torch.cat([x, skip], 1) read in place -- inference 1x1 convs only
             return ops.conv1x1_cat_fwd_h2(ops._c(x[0]), ops._c(x[1]), self.weight.shape, self.packed_weight_h2(),
                                           self.bias, None if residual is None else ops._c(residual))
@@ -118,7 +124,8 @@ class Conv2d(torch.nn.Module):
         if self.weight is not None:
             if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
-                                         None if residual is None else ops._c(residual), x_split, out, qkv_out)
+                                         None if residual is None else ops._c(residual), x_split, out, qkv_out,
+                                         False, up_res)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -197,14 +204,18 @@ class UNetBlock(torch.nn.Module):
         orig = x
         # inference in f16x2 conv math: the norms hand the convs pre-split f16 pairs (no conversion in the conv)
         sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
-        sp0 = sp and not (self.conv0.up or self.conv0.down)
-        x = self.conv0(self.norm0(x, act_silu=True, split_out=sp0), x_split=sp0)
+        # up blocks in that mode: the x2 upsample of conv0's input and of the weight-less skip never hit memory
+        fu = (sp and self.conv0.up and self.skip is not None and self.skip.weight is None and not isinstance(x, tuple)
+              and x.shape[3] * 2 <= 32 and (x.shape[3] & (x.shape[3] - 1)) == 0
+              and not os.environ.get("I2R_NO_FUSE_UP"))
+        sp0 = sp and (fu or not (self.conv0.up or self.conv0.down))
+        x = self.conv0(self.norm0(x, act_silu=True, split_out=sp0), x_split=sp0, fuse_up=fu)
         if params is None:
             params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
         x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0,
                        split_out=sp)
-        skip = self.skip(orig) if self.skip is not None else orig
-        x = self.conv1(x, residual=skip, x_split=sp)
+        skip = orig if (fu or self.skip is None) else self.skip(orig)
+        x = self.conv1(x, residual=skip, x_split=sp, up_res=fu)
         if self.num_heads:
             chunk = self._attn_chunk(x) if sp else 0
             if chunk:

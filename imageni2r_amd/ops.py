@@ -194,13 +194,18 @@ def conv2d_pack_h2(w):
     return wp
 
 
-def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None, qkv_out=False):
+def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None, qkv_out=False, up_in=False,
+                  up_res=False):
     """Inference conv on the f16 matrix cores with fp32-grade accuracy (csrc/conv_fwd_h2.hip).  ``x_split``: x holds
     pre-split f16 pairs (groupnorm_fwd(..., split_out=True)).  ``out``: write into this (B, Cout, H, W) tensor.
-    ``qkv_out``: store the result as split pairs with the q rows pre-scaled, for attention_fwd(presplit=True)."""
+    ``qkv_out``: store the result as split pairs with the q rows pre-scaled, for attention_fwd(presplit=True).
+    ``up_in`` / ``up_res``: x / the residual are at half resolution and are nearest-upsampled x2 on the fly (the
+    ``up=True`` convs and the weight-less skip of the decoder's up blocks, networks.py:79-81, :156-159)."""
     _chk(x, "x")
     Cout, Cin, k, _ = w_shape
     B, Cin2, H, W = x.shape
+    if up_in:
+        H, W = 2 * H, 2 * W
     if Cin2 != Cin:
         raise ValueError("conv2d_fwd_h2: channel mismatch")
     if out is None:
@@ -209,10 +214,14 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=N
         raise ValueError("conv2d_fwd_h2: out has the wrong shape")
     if residual is not None:
         _chk(residual, "residual")
+        want = (B, Cout, H // 2, W // 2) if up_res else (B, Cout, H, W)
+        if tuple(residual.shape) != want:
+            raise ValueError(f"conv2d_fwd_h2: residual shape {tuple(residual.shape)} != {want}")
     nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
     ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
+    flags = int(bool(x_split)) | (2 if qkv_out else 0) | (4 if up_in else 0) | (8 if up_res else 0)
     _lib.call("i2r_conv2d_fwd_h2", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W, Cout, k,
-              int(bool(x_split)) | (2 if qkv_out else 0), _stream())
+              flags, _stream())
     return out
 
 

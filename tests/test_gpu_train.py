@@ -321,3 +321,35 @@ def test_slot_path_gradients_vs_oracle():
         for k, p in m.net.named_parameters():
             assert p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr(), k
             assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-4, (rep, k)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hl,split", [(3, 128, 128, 8, True), (2, 256, 256, 4, False), (2, 64, 96, 16, True),
+                                                  (5, 512, 512, 2, True), (2, 96, 64, 1, False)])
+def test_conv_fused_upsample_input_and_residual(ops, B, Cin, Cout, Hl, split):
+    """The decoder's up blocks in f16x2 inference: the nearest x2 upsample of conv0's input and of conv1's residual
+    happens in the conv's addressing; results equal the materialised-upsample composition."""
+    gen = torch.Generator().manual_seed(Cin + Cout + Hl)
+    x = torch.randn(B, Cin, Hl, Hl, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, Hl, Hl, generator=gen)
+    up = lambda t: t.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    wp = ops.conv2d_pack_h2(cu(w.numpy()))
+    if split:  # GroupNorm hands over split pairs: upsampling them is the same pure copy
+        gw, gb = torch.randn(Cin, generator=gen), torch.randn(Cin, generator=gen)
+        G = min(32, Cin // 4)
+        xin = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double(), G, gw.double(), gb.double(), 1e-5))
+        xd, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, None, True, split_out=True)
+    else:
+        xin, xd = x.double(), cu(x.numpy())
+    ref = torch.nn.functional.conv2d(up(xin), w.double(), b.double(), padding=1) + up(res.double())
+    y = ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, cu(b.numpy()), cu(res.numpy()), x_split=split, up_in=True, up_res=True)
+    assert tuple(y.shape) == (B, Cout, 2 * Hl, 2 * Hl)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-6
+    # residual-only upsampling on a plain conv (conv1 of the up block)
+    x2 = torch.randn(B, Cout, 2 * Hl, 2 * Hl, generator=gen)
+    w2 = torch.randn(Cout, Cout, 3, 3, generator=gen) / np.sqrt(Cout * 9)
+    ref2 = torch.nn.functional.conv2d(x2.double(), w2.double(), b.double(), padding=1) + up(res.double())
+    y2 = ops.conv2d_fwd_h2(cu(x2.numpy()), tuple(w2.shape), ops.conv2d_pack_h2(cu(w2.numpy())), cu(b.numpy()),
+                           cu(res.numpy()), up_res=True)
+    assert rel_err(y2.cpu().numpy(), ref2.numpy()) < 5e-6
