@@ -5,7 +5,8 @@
 // quarter of one for groups of <= 64 elements) owns one (sample, group) and keeps the whole group in REGISTERS: one
 // 16-B-per-lane read of x (and of dy in backward), shuffle reductions, one 16-B-per-lane write.  HBM-bound:
 // 8 B/element forward, 12 B/element backward (+ the small per-channel outputs).
-// Shapes the register kernels do not cover (H*W not a power of two >= 4, groups > 4096 elements) take the generic
+// Shapes the register kernels do not cover (H*W not a power of two >= 4, groups > 4096 elements in backward,
+// > 16384 in forward, where a whole workgroup can own a group) take the generic
 // strided-loop kernels at the bottom.
 #include "i2r_common.h"
 #include "../../include/i2r_hip.h"
@@ -29,6 +30,20 @@ __device__ __forceinline__ float seg_sum(float v) {
 #pragma unroll
   for (int o = LPG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// sum over the LPG lanes that own a group; LPG = 256 is the whole workgroup (groups of 4097..16384 elements: the
+// 32x32 levels of the ETTh1-768 / weather configs), reduced through LDS (SLOT keeps the two uses on separate words)
+template <int LPG, int SLOT>
+__device__ __forceinline__ float grp_sum(float v) {
+  if constexpr (LPG <= 64) {
+    return seg_sum<LPG>(v);
+  } else {
+    __shared__ float red[4];
+    v = seg_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 // sum over aligned runs of `w` lanes (w a power of two <= 64, wave-uniform)
 __device__ __forceinline__ float run_sum(float v, int w) {
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
     v[k] = (valid && i4 * 4 < n) ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
-  const float mean = seg_sum<LPG>(s) / (float)n;
+  const float mean = grp_sum<LPG, 0>(s) / (float)n;
   float q = 0.0f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
       q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
   }
-  const float rstd = 1.0f / sqrtf(seg_sum<LPG>(q) / (float)n + p.eps);
+  const float rstd = 1.0f / sqrtf(grp_sum<LPG, 1>(q) / (float)n + p.eps);
   if (!valid) return;
   if (sl == 0 && p.mean_out) {
     p.mean_out[wg] = mean;
@@ -409,8 +424,8 @@ template <bool BWD>
 static void gn_launch(const GnP& p, hipStream_t s) {
   const long groups = (long)p.B * p.G;
   const int n = (p.C / p.G) * p.HW;
-  const bool reg_ok = p.sh >= 2 && n <= 4096 && (((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.y) & 15) == 0 &&
-                      (!BWD || (((uintptr_t)p.dy) & 15) == 0);
+  const bool reg_ok = p.sh >= 2 && n <= (BWD ? 4096 : 16384) && (((uintptr_t)p.x) & 15) == 0 &&
+                      (((uintptr_t)p.y) & 15) == 0 && (!BWD || (((uintptr_t)p.dy) & 15) == 0);
 #define GN_GO(LPG, NV)                                                                                          \
   do {                                                                                                          \
     dim3 grid(i2r_cdiv(groups, 256 / LPG));                                                                     \
@@ -435,8 +450,12 @@ static void gn_launch(const GnP& p, hipStream_t s) {
     GN_GO(64, 4);
   } else if (n <= 2048) {
     GN_GO(64, 8);
-  } else {
+  } else if (n <= 4096 || BWD) {
     GN_GO(64, 16);
+  } else if (n <= 8192) {
+    if constexpr (!BWD) hipLaunchKernelGGL((gn_fwd_reg_kernel<256, 8>), dim3(groups), dim3(256), 0, s, p);
+  } else {
+    if constexpr (!BWD) hipLaunchKernelGGL((gn_fwd_reg_kernel<256, 16>), dim3(groups), dim3(256), 0, s, p);
   }
 #undef GN_GO
 }
@@ -459,7 +478,7 @@ extern "C" int i2r_groupnorm_fwd_f32(const float* x, const float* gamma, const f
 }
 
 // Forward over the channel concatenation [x1 | x2] (C1 + C2 channels) without materialising it (decoder skips,
-// models/networks.py:458 followed by norm0 at :168).  Register kernels only: H*W a power of two >= 4, groups <= 4096.
+// models/networks.py:458 followed by norm0 at :168).  Register kernels only: H*W a power of two >= 4, groups <= 16384 elements.
 extern "C" int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C1, int C2, const float* gamma,
                                          const float* beta, const float* ss, int ss_batch, float* y, int B, int HW,
                                          int G, float eps, int act, int split_out, i2r_stream_t stream) {
@@ -470,8 +489,8 @@ extern "C" int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C
   GnP p{};
   p.x = x1; p.x2 = x2; p.C1 = C1; p.gamma = gamma; p.beta = beta; p.ss = ss; p.y = y; p.ss_batch = ss_batch;
   p.B = B; p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW); p.act = act; p.eps = eps; p.split_out = split_out;
-  I2R_REQUIRE(p.sh >= 2 && (C / G) * HW <= 4096 && ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)y)) & 15) == 0,
-              "groupnorm_cat_fwd: needs H*W a power of two >= 4 (got %d), groups <= 4096 elements, 16-B aligned "
+  I2R_REQUIRE(p.sh >= 2 && (C / G) * HW <= 16384 && ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)y)) & 15) == 0,
+              "groupnorm_cat_fwd: needs H*W a power of two >= 4 (got %d), groups <= 16384 elements, 16-B aligned "
               "tensors", HW);
   gn_launch<false>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_cat_fwd");

@@ -364,7 +364,7 @@ class DhariwalUNet(torch.nn.Module):
         return ((not torch.is_grad_enabled()) and ops.conv_math() == "f16x2" and hw >= 4 and (hw & (hw - 1)) == 0
                 and x.shape[1] % 16 == 0 and block.skip is not None and block.skip.weight is not None
                 and block.skip.weight.shape[-1] == 1 and not (block.conv0.up or block.conv0.down)
-                and (x.shape[1] + skip.shape[1]) // block.norm0.num_groups * hw <= 4096)
+                and (x.shape[1] + skip.shape[1]) // block.norm0.num_groups * hw <= 16384)
 
     def embed(self, noise_labels):
         """Noise-level embedding (:437-447): posemb -> Linear+SiLU -> Linear+SiLU."""

@@ -28,7 +28,8 @@ def ops():
 
 # (B, C, H): group sizes 16 .. 4096 elements, HW = 1 (generic kernel), 4, 16, 64, 256, 1024; ragged group counts
 @pytest.mark.parametrize("B,C,H", [(3, 128, 16), (2, 128, 32), (2, 256, 32), (5, 1024, 2), (3, 512, 2), (7, 256, 4),
-                                   (2, 384, 8), (3, 256, 1), (1, 768, 4), (2, 1024, 1), (9, 128, 8), (2, 12 * 4, 16)])
+                                   (2, 384, 8), (3, 256, 1), (1, 768, 4), (2, 1024, 1), (9, 128, 8), (2, 12 * 4, 16),
+                                   (2, 384, 32), (1, 512, 32)])
 def test_groupnorm_register_kernels_all_geometries(ops, B, C, H):
     gen = torch.Generator().manual_seed(B * 100 + C + H)
     x = torch.randn(B, C, H, H, generator=gen) * 1.7 + 0.3
@@ -165,6 +166,7 @@ def test_qkv_conv_split_output_feeds_presplit_attention(ops, B, C, H):
 
 
 @pytest.mark.parametrize("B,C1,C2,H,Cout", [(3, 256, 128, 8, 256), (2, 512, 512, 2, 512), (2, 256, 256, 4, 256),
+                                            (2, 256, 128, 32, 128), (1, 128, 128, 32, 128),
                                             (5, 128, 128, 16, 128), (2, 64, 32, 8, 64)])
 def test_concat_free_groupnorm_and_skip_conv(ops, B, C1, C2, H, Cout):
     """Decoder skip connections without materialising torch.cat (networks.py:458): GroupNorm and the 1x1 skip conv
