@@ -19,6 +19,7 @@
 #include "i2r_common.h"
 #include "../../include/i2r_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -100,9 +101,15 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
     rvoff = nvalid ? ((pb * (unsigned)p.Cout + (unsigned)(m0 + 4 * h)) * hwl + (y >> 1) * ((unsigned)p.W >> 1) + (x >> 1)) * 4u
                    : OOR;
   }
-  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)res_bytes, 0x00020000);
   const int lim = p.Cout - m0 - 4 * h;  // channel offsets below lim exist
   const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
+  __amdgpu_buffer_rsrc_t rR =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, use_res ? (int)res_bytes : 0, 0x00020000);
+  // bias (and residual, above) through a buffer descriptor of size 0 when there is none (or on split-K partials): every lane-level
+  // condition is an out-of-range offset instead of a branch around a load (the branchy form cost ~7 us per workgroup)
+  __amdgpu_buffer_rsrc_t rBias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
+  const unsigned boff = (unsigned)(m0 + 4 * h) * 4u;
   const int cmod = (m0 + 4 * h) % 3;  // (head, d, {q,k,v}) interleave: channel % 3 == 0 is a q row
   float bv[4][16], rv[4][16];
 #pragma unroll
@@ -111,22 +118,26 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
     for (int r = 0; r < 16; ++r) {
       const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
       const bool ok = cof < lim;
-      bv[t][r] = (use_bias && ok) ? p.bias[m0 + 4 * h + cof] : 0.0f;
-      rv[t][r] = use_res ? bufload(rR, ok ? rvoff : OOR, (unsigned)cof * rplane) : 0.0f;
+      bv[t][r] = bufload(rBias, ok ? boff : OOR, (unsigned)cof * 4u);  // branch-free: out of range reads 0
+      rv[t][r] = bufload(rR, ok ? rvoff : OOR, (unsigned)cof * rplane);
     }
+  auto store_all = [&](auto qkv) {  // one straight-line run of 64 stores per output form (no per-element branch)
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
-      float v = acc[t][r] * WSCALE_INV + bv[t][r] + rv[t][r];
-      if (p.qkv_out) {
-        if ((cmod + cof) % 3 == 0) v *= I2R_QSCALE;
-        v = split_pack(v);
+      for (int r = 0; r < 16; ++r) {
+        const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[t][r] * WSCALE_INV + bv[t][r] + rv[t][r];
+        if (decltype(qkv)::value) {
+          if ((cmod + cof) % 3 == 0) v *= I2R_QSCALE;
+          v = split_pack(v);
+        }
+        unsigned vo = (cof < lim && (!(ablate & 1) || v == 12345.678f)) ? voff : OOR;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, vo, (unsigned)cof * plane, 0);
       }
-      unsigned vo = (cof < lim && (!(ablate & 1) || v == 12345.678f)) ? voff : OOR;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, vo, (unsigned)cof * plane, 0);
-    }
+  };
+  if (p.qkv_out) store_all(std::true_type{});
+  else store_all(std::false_type{});
 }
 
 // value of lane-1 / lane+1 (0 into the wave's first / last lane): DPP wave shifts, no LDS, no memory
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
           const int cbase = c * 64 + q * 16;
           const bool first = cbase < p.Cin1;  // wave-uniform
           unsigned sB = (unsigned)((first ? cbase : cbase - p.Cin1) + j) * chan_bytes + dead;
-          rb[q][j] = first ? bufload(rB, voffB[0], sB) : bufload(rB2, voffB2, sB);
+          rb[q][j] = bufload(first ? rB : rB2, first ? voffB[0] : voffB2, sB);  // scalar selects, no branch
         }
     }
   };
