@@ -140,6 +140,90 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
   else store_all(std::false_type{});
 }
 
+// Same epilogue with 16-byte global accesses.  The vector-memory INSTRUCTION count, not bytes, bounds the short-K
+// convs: the lane-per-position form above issues 64 dword stores + 64 bias + 64 residual loads per tile and lane; a
+// workgroup that does nothing else still takes ~6 us (measured with the main loop and the stores compiled out), on a
+// par with the whole MFMA loop of a 128-channel 1x1 conv.  Here each 32-channel x 32-position accumulator tile
+// is transposed through a private 4.5 KB LDS patch (the weight stages are idle by now) so that a lane owns FOUR
+// consecutive positions of one channel: 16 b128 stores + 16 b128 residual loads + 16 bias loads per tile.
+// Needs W % 4 == 0 (a position quad inside one image row).  `scratch`: this wave's 32 x 36 floats.
+#define EPI_PITCH 36
+__device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
+                                                 long nw, int m0, int lane, float* scratch, int ablate) {
+  const int l31 = lane & 31, h = lane >> 5, cr = lane >> 3, pq = (lane & 7) * 4;
+  const long nq = nw + pq;
+  const bool qvalid = nq < p.Npos;
+  unsigned pb = 0, pos = 0;
+  if (qvalid) {
+    pb = (unsigned)(nq / p.HW);
+    pos = (unsigned)(nq - (long)pb * p.HW);
+  }
+  const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
+  const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
+  const unsigned plane = (unsigned)p.HW * 4;
+  const unsigned crow = pb * (unsigned)p.Cout + (unsigned)(m0 + cr);  // (sample, channel) plane index of this lane
+  const unsigned voff = qvalid ? (crow * (unsigned)p.HW + pos) * 4u : OOR;
+  unsigned rplane = plane, rvoff = voff, res_bytes = out_bytes;
+  if (p.up_res) {  // half-resolution residual: the quad's sources are pixels (x0/2, x0/2 + 1) of row y/2
+    const unsigned y = pos / (unsigned)p.W, x = pos - y * (unsigned)p.W, hwl = (unsigned)p.HW >> 2;
+    rplane = hwl * 4;
+    res_bytes = out_bytes >> 2;
+    rvoff = qvalid ? (crow * hwl + (y >> 1) * ((unsigned)p.W >> 1) + (x >> 1)) * 4u : OOR;
+  }
+  __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rR =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, use_res ? (int)res_bytes : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rBias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
+  const int lim = p.Cout - m0 - cr;  // channel offsets below lim exist for this lane
+  const unsigned boff = (unsigned)(m0 + cr) * 4u;
+  const int cmod = (m0 + cr) % 3;
+  // every load before the first store (see the aliasing note above)
+  float bv[16], rv[16][4];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
+  if (p.up_res) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // tile t = q / 4 covers channel offsets 32 t + 8 i + cr = 8 q + cr
+      const float a = bufload(rR, 8 * q < lim ? rvoff : OOR, (unsigned)(8 * q) * rplane);
+      const float b = bufload(rR, 8 * q < lim ? rvoff + 4u : OOR, (unsigned)(8 * q) * rplane);
+      rv[q][0] = a; rv[q][1] = a; rv[q][2] = b; rv[q][3] = b;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint4v t4 = bufload4(rR, 8 * q < lim ? rvoff : OOR, (unsigned)(8 * q) * rplane);
+      // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+      const unsigned u0 = t4.x, u1 = t4.y, u2 = t4.z, u3 = t4.w;
+      rv[q][0] = __builtin_bit_cast(float, u0); rv[q][1] = __builtin_bit_cast(float, u1);
+      rv[q][2] = __builtin_bit_cast(float, u2); rv[q][3] = __builtin_bit_cast(float, u3);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_PITCH + l31] = acc[t][r];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 4 * t + i, cof = 8 * q;
+      const float4 a = *reinterpret_cast<const float4*>(scratch + (8 * i + cr) * EPI_PITCH + pq);
+      float v[4] = {a.x, a.y, a.z, a.w};
+      uint4v o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = v[e] * WSCALE_INV + bv[q] + rv[q][e];
+        if (p.qkv_out) {
+          if ((cmod + cof) % 3 == 0) y *= I2R_QSCALE;
+          y = split_pack(y);
+        }
+        o[e] = __builtin_bit_cast(unsigned, y);
+      }
+      unsigned vo = (cof < lim && (!(ablate & 1) || o[0] == 0x12345678u)) ? voff : OOR;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rO, vo, (unsigned)cof * plane, 0);
+    }
+  }
+}
+
 // value of lane-1 / lane+1 (0 into the wave's first / last lane): DPP wave shifts, no LDS, no memory
 __device__ __forceinline__ float from_lane_below(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -384,7 +468,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 
   const bool direct = p.nsplit == 1;
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
-  h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate);
+  if ((p.W & 3) == 0 && !(p.ablate & 8))  // quad form: its LDS patch reuses the (now idle) weight stages
+    h2_epilogue_quad(p, acc, outp, direct, n0 + wave * 32, m0, lane,
+                     reinterpret_cast<float*>(smem) + wave * (32 * EPI_PITCH), p.ablate);
+  else
+    h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate);
 }
 
 // out = sum_z slab[z] + bias + residual
