@@ -173,6 +173,8 @@ static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
   static const long target = getenv("I2R_WGRAD_TARGET") ? atol(getenv("I2R_WGRAD_TARGET")) : 1024;
   long want = (target + tiles - 1) / tiles;  // aim for ~4 blocks per CU
   if (want > total_chunks / 4) want = total_chunks / 4;  // keep >= 4 chunks per split
+  static const long maxsplit = getenv("I2R_WGRAD_MAXSPLIT") ? atol(getenv("I2R_WGRAD_MAXSPLIT")) : 1 << 20;
+  if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;
   p.chunks_per_split = (int)((total_chunks + want - 1) / want);
   p.nsplit = (int)((total_chunks + p.chunks_per_split - 1) / p.chunks_per_split);

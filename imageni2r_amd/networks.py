@@ -383,9 +383,12 @@ class DhariwalUNet(torch.nn.Module):
                              getattr(l.bias, "_grad_slot", None) is None for l in lins):
             return None
         key = ops.AffinePlan.make_key(lins, emb.shape[0])
-        plan = getattr(self, "_affine_plan", None)
-        if plan is None or plan.key != key:
-            plan = self._affine_plan = ops.AffinePlan(lins, emb.shape[0])
+        plans = self.__dict__.setdefault("_affine_plans", {})  # per (batch rows, parameter / slot addresses)
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) >= 8:
+                plans.clear()
+            plan = plans[key] = ops.AffinePlan(lins, emb.shape[0])
         flat = [t for l in lins for t in (l.weight, l.bias)]
         outs = ops.AffineAllFn.apply(emb, plan, *flat)
         if need_grad and outs[0].grad_fn is not None:
