@@ -42,8 +42,8 @@ SIGNATURES = {
     "i2r_split_channels_f32": [P, P, P, I, L, L, I, P],
     "i2r_groupnorm_fwd_f32": [P, P, P, P, I, P, P, P, I, I, I, I, F, I, F, U, U, P, I, P],
     "i2r_groupnorm_cat_fwd_f32": [P, P, I, I, P, P, P, I, P, I, I, I, F, I, I, P],
-    "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
-    "i2r_groupnorm_bwd_acc_f32": [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
+    "i2r_groupnorm_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
+    "i2r_groupnorm_bwd_acc_f32": [P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U, U, P, P],
     "i2r_reduce_rows_f32": [P, P, I, I, P],
     "i2r_reduce_rows2_f32": [P, P, P, I, I, I, P],
     "i2r_attention_fwd_f32": [P, P, P, I, I, I, P],

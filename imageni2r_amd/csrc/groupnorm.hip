@@ -69,6 +69,7 @@ struct GnP {
   float* dg_acc;        // backward: (C) dgamma / dbeta accumulated with fp32 atomics over the batch (pre-zeroed by
   float* db_acc;        //           the caller: the step's gradient slots) -- saves the (B, 2C) partials + a reduction
   float* dss;           // backward: (B, 2C) [dscale | dshift]
+  const float* add;     // backward, optional (B, C, HW): added to dx (the gradient of the block's bypass of x)
   const uint64_t* rng_step;
   int ss_batch, B, C, C1, HW, G, sh, act, split_out;
   float eps, drop_p;
@@ -250,8 +251,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
   for (int k = 0; k < NV; ++k) {
     int i4 = sl + LPG * k;
     if (i4 * 4 >= n) continue;
-    dxp[i4] = make_float4(rstd * (dn[k].x - m1 - xh[k].x * m2), rstd * (dn[k].y - m1 - xh[k].y * m2),
-                          rstd * (dn[k].z - m1 - xh[k].z * m2), rstd * (dn[k].w - m1 - xh[k].w * m2));
+    float4 o = make_float4(rstd * (dn[k].x - m1 - xh[k].x * m2), rstd * (dn[k].y - m1 - xh[k].y * m2),
+                           rstd * (dn[k].z - m1 - xh[k].z * m2), rstd * (dn[k].w - m1 - xh[k].w * m2));
+    if (p.add) {
+      const float4 a = reinterpret_cast<const float4*>(p.add + base)[i4];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    dxp[i4] = o;
   }
 }
 
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) void groupnorm_bwd_kernel(GnP p) {
       du *= dsilu_f(u);
     }
     float dxh = du * sc1 * gm;
-    p.y[base + i] = rstd * (dxh - m1 - xh * m2);
+    p.y[base + i] = rstd * (dxh - m1 - xh * m2) + (p.add ? p.add[base + i] : 0.0f);
   }
 }
 
@@ -425,7 +431,7 @@ static void gn_launch(const GnP& p, hipStream_t s) {
   const long groups = (long)p.B * p.G;
   const int n = (p.C / p.G) * p.HW;
   const bool reg_ok = p.sh >= 2 && n <= (BWD ? 4096 : 16384) && (((uintptr_t)p.x) & 15) == 0 &&
-                      (((uintptr_t)p.y) & 15) == 0 && (!BWD || (((uintptr_t)p.dy) & 15) == 0);
+                      (((uintptr_t)p.y) & 15) == 0 && (!BWD || ((((uintptr_t)p.dy) | ((uintptr_t)p.add)) & 15) == 0);
 #define GN_GO(LPG, NV)                                                                                          \
   do {                                                                                                          \
     dim3 grid(i2r_cdiv(groups, 256 / LPG));                                                                     \
@@ -498,15 +504,16 @@ extern "C" int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C
 
 extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss,
                                      int ss_batch, const float* mean, const float* rstd, const float* dy, float* dx,
-                                     float* dgb_part, float* dss, int B, int C, int HW, int G, int act, float drop_p,
-                                     uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream) {
+                                     float* dgb_part, float* dss, const float* dx_add, int B, int C, int HW, int G,
+                                     int act, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                                     i2r_stream_t stream) {
   I2R_REQUIRE(x && gamma && beta && mean && rstd && dy && dx && dgb_part, "groupnorm_bwd: null pointer");
   I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_bwd: C=%d not divisible by G=%d", C, G);
   I2R_REQUIRE(!ss || ss_batch == B, "groupnorm_bwd: scale/shift must be per-sample (batch %d vs %d)", ss_batch, B);
   I2R_REQUIRE((ss != nullptr) == (dss != nullptr), "groupnorm_bwd: dss must be given iff ss is");
   GnP p{};
   p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.mean_in = mean; p.rstd_in = rstd; p.dy = dy; p.y = dx;
-  p.dgb_part = dgb_part; p.dss = dss; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B; p.C = C; p.HW = HW;
+  p.dgb_part = dgb_part; p.dss = dss; p.add = dx_add; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B; p.C = C; p.HW = HW;
   p.G = G; p.sh = pow2_shift(HW); p.act = act; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   gn_launch<true>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_bwd");
@@ -516,9 +523,10 @@ extern "C" int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const f
 // no (B, 2C) partial tensor and no reduction launch.  Summation order over the batch is not fixed.
 extern "C" int i2r_groupnorm_bwd_acc_f32(const float* x, const float* gamma, const float* beta, const float* ss,
                                          int ss_batch, const float* mean, const float* rstd, const float* dy,
-                                         float* dx, float* dgamma_acc, float* dbeta_acc, float* dss, int B, int C,
-                                         int HW, int G, int act, float drop_p, uint64_t seed, uint64_t offset,
-                                         const uint64_t* rng_step, i2r_stream_t stream) {
+                                         float* dx, float* dgamma_acc, float* dbeta_acc, float* dss,
+                                         const float* dx_add, int B, int C, int HW, int G, int act, float drop_p,
+                                         uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                                         i2r_stream_t stream) {
   I2R_REQUIRE(x && gamma && beta && mean && rstd && dy && dx && dgamma_acc && dbeta_acc,
               "groupnorm_bwd_acc: null pointer");
   I2R_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "groupnorm_bwd_acc: C=%d not divisible by G=%d", C, G);
@@ -526,7 +534,7 @@ extern "C" int i2r_groupnorm_bwd_acc_f32(const float* x, const float* gamma, con
   I2R_REQUIRE((ss != nullptr) == (dss != nullptr), "groupnorm_bwd_acc: dss must be given iff ss is");
   GnP p{};
   p.x = x; p.gamma = gamma; p.beta = beta; p.ss = ss; p.mean_in = mean; p.rstd_in = rstd; p.dy = dy; p.y = dx;
-  p.dg_acc = dgamma_acc; p.db_acc = dbeta_acc; p.dss = dss; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B;
+  p.dg_acc = dgamma_acc; p.db_acc = dbeta_acc; p.dss = dss; p.add = dx_add; p.rng_step = rng_step; p.ss_batch = ss_batch; p.B = B;
   p.C = C; p.HW = HW; p.G = G; p.sh = pow2_shift(HW); p.act = act; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   gn_launch<true>(p, (hipStream_t)stream);
   return i2r_check_launch("groupnorm_bwd_acc");

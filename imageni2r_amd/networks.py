@@ -142,7 +142,7 @@ class GroupNorm(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(num_channels))
         self._rng_id = next(_layer_ids)  # fixed Philox stream id of this layer's dropout (device-step RNG mode)
 
-    def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0, split_out=False):
+    def forward(self, x, scale_shift=None, act_silu=False, drop_p=0.0, split_out=False, bypass=False):
         """group_norm (:104-106), optionally fused with (1+scale)*y+shift, SiLU and dropout of its consumer.
         ``split_out`` (inference only): emit f16 hi/lo pairs for a following f16x2 conv instead of fp32."""
         if isinstance(x, tuple):  # (x, skip): the decoder's channel concat, never materialised (inference only)
@@ -158,7 +158,7 @@ class GroupNorm(torch.nn.Module):
             # host counter per call, or (device step counter, fixed layer id) when a graph owns the RNG step
             offset = self._rng_id if ops.rng_step() is not None else next(_dropout_counter)
         return ops.GroupNormFn.apply(x, self.weight, self.bias, scale_shift, self.num_groups, self.eps, act_silu,
-                                     drop_p, seed, offset)
+                                     drop_p, seed, offset, bypass)
 
 
 class UNetBlock(torch.nn.Module):
@@ -209,7 +209,14 @@ class UNetBlock(torch.nn.Module):
               and x.shape[3] * 2 <= 32 and (x.shape[3] & (x.shape[3] - 1)) == 0
               and not os.environ.get("I2R_NO_FUSE_UP"))
         sp0 = sp and (fu or not (self.conv0.up or self.conv0.down))
-        x = self.conv0(self.norm0(x, act_silu=True, split_out=sp0), x_split=sp0, fuse_up=fu)
+        # training: the residual / skip branch leaves through norm0's bypass output, so x has one consumer and its two
+        # gradients are summed inside the GroupNorm backward kernel instead of by an autograd accumulation kernel
+        byp = torch.is_grad_enabled() and not isinstance(x, tuple) and not os.environ.get("I2R_NO_GN_BYPASS")
+        if byp:
+            h0, orig = self.norm0(x, act_silu=True, bypass=True)
+        else:
+            h0 = self.norm0(x, act_silu=True, split_out=sp0)
+        x = self.conv0(h0, x_split=sp0, fuse_up=fu)
         if params is None:
             params = self.affine(emb)  # (B or 1, 2*Cout) = [scale | shift] (:170-172)
         x = self.norm1(x, scale_shift=params, act_silu=True, drop_p=self.dropout if self.training else 0.0,
@@ -226,7 +233,11 @@ class UNetBlock(torch.nn.Module):
                     xc = x[i:i + chunk]
                     self.proj(self._attend(xc, True), residual=xc, out=out[i:i + chunk])
                 return out
-            x = self.proj(self._attend(x, sp), residual=x)
+            if byp:
+                xn, xb = self.norm2(x, bypass=True)
+                x = self.proj(ops.AttentionFn.apply(self.qkv(xn), self.num_heads), residual=xb)
+            else:
+                x = self.proj(self._attend(x, sp), residual=x)
         return x
 
     def _attend(self, x, sp):

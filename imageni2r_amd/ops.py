@@ -341,10 +341,13 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, ss=None, act=False, save_stats=Fa
 
 
 def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, seed=0, offset=0, step=None,
-                  dgamma=None, dbeta=None, dss=None):
+                  dgamma=None, dbeta=None, dss=None, add=None):
+    """``add``: a (B, C, H, W) gradient added to dx in the same pass (the block's bypass of x)."""
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     _chk(dy, "dy")
+    if add is not None and (tuple(_chk(add, "add").shape) != tuple(x.shape)):
+        raise ValueError("groupnorm_bwd: add has the wrong shape")
     dx = torch.empty_like(x)
     if ss is None:
         dss = None
@@ -353,12 +356,12 @@ def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, s
     if dgamma is not None and dbeta is not None and slots_zeroed():
         # the step's gradient slots were zero-filled: accumulate over the batch in place (no partials, no reduction)
         _lib.call("i2r_groupnorm_bwd_acc_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0],
-                  _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dss), B, C, HW, groups,
+                  _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dss), _p(add), B, C, HW, groups,
                   int(bool(act)), float(drop_p), int(seed), int(offset), _p(step), _stream())
         return dx, dgamma, dbeta, dss
     part = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)  # per-sample [dgamma | dbeta]
     _lib.call("i2r_groupnorm_bwd_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0], _p(mean),
-              _p(rstd), _p(dy), _p(dx), _p(part), _p(dss), B, C, HW, groups, int(bool(act)),
+              _p(rstd), _p(dy), _p(dx), _p(part), _p(dss), _p(add), B, C, HW, groups, int(bool(act)),
               float(drop_p), int(seed), int(offset), _p(step), _stream())
     if dgamma is not None and dbeta is not None:  # straight into the parameters' gradient slots
         _lib.call("i2r_reduce_rows2_f32", _p(part), _p(dgamma), _p(dbeta), B, C, C, _stream())
@@ -609,7 +612,10 @@ class GroupNormFn(torch.autograd.Function):
     """gn -> (1+scale)*.+shift -> SiLU -> dropout, one kernel each way."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, eps, act, drop_p, seed, offset):
+    def forward(ctx, x, gamma, beta, ss, groups, eps, act, drop_p, seed, offset, bypass=False):
+        """``bypass``: also return x itself as a second output.  The block routes its residual / skip branch through
+        that alias, so x has ONE consumer in the autograd graph and the two gradients are summed inside the backward
+        kernel (``add``) instead of by a separate accumulation kernel."""
         x = _c(x)
         need_bwd = any(ctx.needs_input_grad[:4])
         dss_slot = getattr(ss, "_dss_slot", None)  # AffineAllFn's dy slab piece for this layer, if grouped
@@ -622,10 +628,10 @@ class GroupNormFn(torch.autograd.Function):
             ctx.cfg = (groups, act, drop_p, seed, offset, step)
             ctx.slots = (getattr(gamma, "_grad_slot", None), getattr(beta, "_grad_slot", None))
             ctx.dss_slot = dss_slot
-        return y
+        return (y, x.view_as(x)) if bypass else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dbypass=None):
         x, gamma, beta, ss, mean, rstd = ctx.saved_tensors
         groups, act, drop_p, seed, offset, step = ctx.cfg
         if ss is not None and ss.shape[0] != x.shape[0]:
@@ -634,8 +640,8 @@ class GroupNormFn(torch.autograd.Function):
         use = sg is not None and sb is not None
         dx, dg, db, dss = groupnorm_bwd(x, gamma, beta, ss, mean, rstd, _c(dy), groups, act, drop_p, seed, offset,
                                         step, sg.detach() if use else None, sb.detach() if use else None,
-                                        dss=ctx.dss_slot)
-        return dx, dg, db, dss, None, None, None, None, None, None
+                                        dss=ctx.dss_slot, add=None if dbypass is None else _c(dbypass))
+        return dx, dg, db, dss, None, None, None, None, None, None, None
 
 
 class AttentionFn(torch.autograd.Function):

@@ -109,17 +109,19 @@ int i2r_groupnorm_cat_fwd_f32(const float* x1, const float* x2, int C1, int C2, 
                               const float* ss, int ss_batch, float* y, int B, int HW, int G, float eps, int act,
                               int split_out, i2r_stream_t stream);
 /* backward: dx (B,C,HW); dgb_part (B,2C) per-sample [dgamma | dbeta] partials (reduce with i2r_reduce_rows_f32);
- * dss (B,2C) = [dscale | dshift] iff ss given. */
+ * dss (B,2C) = [dscale | dshift] iff ss given; dx_add (B,C,HW) or NULL is added to dx (the gradient that reaches x
+ * through the block's residual / skip bypass, :166-187: saves autograd's separate accumulation pass). */
 int i2r_groupnorm_bwd_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
                           const float* mean, const float* rstd, const float* dy, float* dx, float* dgb_part,
-                          float* dss, int B, int C, int HW, int G, int act, float drop_p, uint64_t seed,
-                          uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
+                          float* dss, const float* dx_add, int B, int C, int HW, int G, int act, float drop_p,
+                          uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
 /* same backward with dgamma / dbeta ADDED by fp32 atomics into caller-zeroed (C) buffers (the training step's
  * gradient slots): no per-sample partials, no reduction launch; batch summation order is not fixed. */
 int i2r_groupnorm_bwd_acc_f32(const float* x, const float* gamma, const float* beta, const float* ss, int ss_batch,
                               const float* mean, const float* rstd, const float* dy, float* dx, float* dgamma_acc,
-                              float* dbeta_acc, float* dss, int B, int C, int HW, int G, int act, float drop_p,
-                              uint64_t seed, uint64_t offset, const uint64_t* rng_step, i2r_stream_t stream);
+                              float* dbeta_acc, float* dss, const float* dx_add, int B, int C, int HW, int G, int act,
+                              float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_step,
+                              i2r_stream_t stream);
 int i2r_reduce_rows_f32(const float* in, float* out, int rows, int cols, i2r_stream_t stream);
 /* same with the columns split over two outputs: [0,cols_a) -> out_a, [cols_a, cols_a+cols_b) -> out_b */
 int i2r_reduce_rows2_f32(const float* in, float* out_a, float* out_b, int rows, int cols_a, int cols_b,
