@@ -249,7 +249,7 @@ class UNetBlock(torch.nn.Module):
             return ops.attention_fwd(qkv, self.num_heads, presplit=pre)[0]
         return ops.AttentionFn.apply(self.qkv(self.norm2(x)), self.num_heads)
 
-    ATTN_CHUNK_BYTES = 256e6  # qkv bytes per chunk of the chunked attention tail (0 disables chunking)
+    ATTN_CHUNK_BYTES = float(os.environ.get("I2R_ATTN_CHUNK_MB", 256)) * 1e6  # qkv bytes per chunk of the chunked attention tail (0 disables chunking)
 
     def _attn_chunk(self, x):
         per_sample = 3 * x.shape[1] * x.shape[2] * x.shape[3] * 4
