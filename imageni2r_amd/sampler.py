@@ -7,6 +7,8 @@ the per-step tensor->bool host syncs (:50) are gone (the schedule lives on the h
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -43,7 +45,7 @@ class DiffusionProcess:
         self.num_steps = args.diffusion_steps
         self.use_graph = use_graph
         self._graphs = {}
-        self.dual_stream_min = 2048  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
+        self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
         self._streams = None
 
     # ------------------------------------------------------------------------------------------------------
