@@ -64,6 +64,22 @@ class LitEma(nn.Module):
                 p.data.copy_(s.data)
         ops.new_pack_epoch()  # .data writes do not bump _version: drop every cached packed conv weight
 
+    def swap(self, model):
+        """Exchange the storage of every parameter with its shadow buffer (no copy, no extra memory): the module then
+        computes with the EMA weights and the shadow buffers hold the training weights, until the next ``swap``.
+        What ``ema_scope`` uses instead of the reference's store + copy_to + restore (models/our.py:87-108: three
+        whole-model copies per evaluation).  Addresses come back exactly after the second swap, so pointer tables
+        built outside the scope (FusedAdamW, captured graphs) stay valid."""
+        from . import ops
+        with torch.no_grad():
+            for s, p in self._pairs(model):
+                if s.shape != p.shape or s.dtype != p.dtype or s.device != p.device:
+                    raise RuntimeError("LitEma.swap: shadow buffer and parameter differ in shape/dtype/device")
+                held = p.data
+                p.data = s.data
+                s.data = held
+        ops.new_pack_epoch()
+
     def store(self, parameters):
         self.collected_params = [param.clone() for param in parameters]
 

@@ -7,6 +7,7 @@ Same constructor (``args`` namespace, ``device``), attributes and methods: ``net
 from __future__ import annotations
 
 import itertools
+import os
 from contextlib import contextmanager
 
 import torch
@@ -97,16 +98,27 @@ class TS2img_Karras(nn.Module):
     # -- EMA ----------------------------------------------------------------------------------------------------
     @contextmanager
     def ema_scope(self, context=None):
+        """Run the body with the EMA weights in ``self.net`` (our.py:87-108).  The reference stores a copy of the
+        training weights, copies the shadow weights in and copies the stored ones back; here the two sets exchange
+        storage (LitEma.swap) -- same weights inside and after the scope, no copies.  ``I2R_EMA_SCOPE=copy`` keeps the
+        reference's sequence (needed only by a caller that reads ``model_ema``'s buffers *inside* the scope)."""
+        swap = self.use_ema and os.environ.get("I2R_EMA_SCOPE", "swap") != "copy"
         if self.use_ema:
-            self.model_ema.store(self.net.parameters())
-            self.model_ema.copy_to(self.net)
+            if swap:
+                self.model_ema.swap(self.net)
+            else:
+                self.model_ema.store(self.net.parameters())
+                self.model_ema.copy_to(self.net)
             if context is not None:
                 print(f"{context}: Switched to EMA weights")
         try:
             yield None
         finally:
             if self.use_ema:
-                self.model_ema.restore(self.net.parameters())
+                if swap:
+                    self.model_ema.swap(self.net)
+                else:
+                    self.model_ema.restore(self.net.parameters())
                 if context is not None:
                     print(f"{context}: Restored training weights")
 

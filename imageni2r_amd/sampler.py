@@ -44,7 +44,10 @@ class DiffusionProcess:
         self.S_noise = 1
         self.num_steps = args.diffusion_steps
         self.use_graph = use_graph
-        self._graphs = {}
+        # captured loops live on the denoiser, not on this object: run_irregular.py:253 builds a new DiffusionProcess
+        # at every evaluation, and with the pointer-swapped ema_scope the weights it sees sit at the same addresses
+        # each time, so the second evaluation replays the first one's graphs
+        self._graphs = self.net.__dict__.setdefault("_i2r_sampler_graphs", {})
         self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
         self._streams = None
 
@@ -75,7 +78,7 @@ class DiffusionProcess:
 
     def _graph_entry(self, latents, t_steps, t_host, slot=0):
         """(graph, static_in, static_out, sigma table) for this batch shape, captured on first use."""
-        key = self._graph_key(latents) + (slot,)
+        key = self._graph_key(latents) + (slot, tuple(t_host))
         entry = self._graphs.get(key)
         if entry is None:
             sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)

@@ -435,12 +435,51 @@ def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
     two = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8))
     two.dual_stream_min = 4
     out = two.sample(xT)
-    assert len(two._graphs) == 2 and tuple(out.shape) == (8, 3, 8, 8)
+    halves = [k for k in two._graphs if k[0] == (4, 3, 8, 8)]  # (the graph cache lives on the net, shared by both)
+    assert len(halves) == 2 and tuple(out.shape) == (8, 3, 8, 8)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
     assert torch.equal(out, two.sample(xT))
     g = load_golden("g5_sampler.npz")  # and the golden pair still comes out right through the split path
     two.dual_stream_min = 2
     assert rel_err(two.sample(torch.from_numpy(g["xT"])).cpu().numpy(), g["out"]) < TOL
+
+
+def test_ema_scope_swap_samples_with_ema_weights_and_reuses_graphs(monkeypatch):
+    """run_irregular.py:250-259: a new DiffusionProcess per evaluation inside ``ema_scope``.  The pointer-swapped scope
+    gives the same series as the reference's copy sequence, the second evaluation replays the first one's graph, and
+    after shadow weights change (training in between) the replay follows them."""
+    from imageni2r_amd import DiffusionProcess, TS2img_Karras
+    torch.manual_seed(11)
+    m = TS2img_Karras(tiny_args(device=DEV), DEV).to(DEV)  # as run_irregular.py:114 does
+    with torch.no_grad():
+        for p in m.net.parameters():  # zero-init layers would make every denoiser output trivial
+            if float(p.abs().max()) == 0:
+                p.normal_(0, 0.05)
+        for b in m.model_ema.buffers():
+            if b.dtype == torch.float32 and b.ndim > 0:
+                b.copy_(torch.randn_like(b) * 0.05)
+    args = tiny_args(device=DEV)
+    xT = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(3))
+    live = DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT)
+    monkeypatch.setenv("I2R_EMA_SCOPE", "copy")
+    with m.ema_scope():
+        ref = DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT)
+    monkeypatch.setenv("I2R_EMA_SCOPE", "swap")
+    assert not torch.equal(ref, live)
+    with m.ema_scope():
+        out = DiffusionProcess(args, m.net, (3, 8, 8)).sample(xT)
+    n_graphs = len(m.net._i2r_sampler_graphs)
+    assert torch.equal(out, ref)  # same kernels, same weights: bit-equal
+    assert torch.equal(DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT), live)  # weights are back
+    with torch.no_grad():
+        for b in m.model_ema.buffers():
+            if b.dtype == torch.float32 and b.ndim > 0:
+                b.mul_(1.5)
+    with m.ema_scope():
+        out2 = DiffusionProcess(args, m.net, (3, 8, 8)).sample(xT)
+        ref2 = DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT)
+    assert len(m.net._i2r_sampler_graphs) == n_graphs == 1
+    assert torch.equal(out2, ref2) and not torch.equal(out2, out)
 
 
 def test_training_step_with_dropout_runs(tiny_gpu):

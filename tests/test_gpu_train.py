@@ -288,6 +288,53 @@ def test_graphed_train_step_matches_eager():
     assert len(set(np.round(lg, 6))) > 1  # noise / sigma draws differ between replays
 
 
+def test_ema_scope_between_graphed_steps(monkeypatch):
+    """Evaluation inside the pointer-swapped ``ema_scope`` between replayed training steps: it samples with the shadow
+    weights the fused optimiser tail has been updating, gives exactly what the reference's copy sequence gives, and
+    leaves every address the training graph and the optimiser's pointer table hold as it was."""
+    from imageni2r_amd import DiffusionProcess, FusedAdamW, GraphedTrainStep, TS2img_Karras
+    torch.manual_seed(0)
+    args = tiny_args(device=DEV)
+    m = TS2img_Karras(args, DEV)
+    O.perturb_zero_init(m.net.state_dict(), seed=1234)
+    m = m.to(DEV).train()
+    opt = FusedAdamW(m.net.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    step = GraphedTrainStep(m, opt)
+    gen = torch.Generator().manual_seed(5)
+
+    def batch():
+        ts = torch.rand(4, 24, 3, generator=gen)
+        ts[1, [5, 6], :] = float("nan")
+        _, mask = m.ts_to_img_with_mask(ts.to(DEV))
+        return m.ts_to_img(torch.rand(4, 24, 3, generator=gen).to(DEV)), mask
+
+    for _ in range(3):
+        step(*batch())
+    key = opt._table_key
+    ptrs = [p.data_ptr() for p in m.net.parameters()]
+    xT = torch.randn(2, 3, 8, 8, generator=gen)
+    m.eval()
+    with m.ema_scope():
+        out_swap = DiffusionProcess(args, m.net, (3, 8, 8)).sample(xT)
+    monkeypatch.setenv("I2R_EMA_SCOPE", "copy")
+    with m.ema_scope():
+        out_copy = DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT)
+    monkeypatch.delenv("I2R_EMA_SCOPE")
+    out_live = DiffusionProcess(args, m.net, (3, 8, 8), use_graph=False).sample(xT)
+    assert torch.equal(out_swap, out_copy) and not torch.equal(out_swap, out_live)
+    m.train()
+    assert ptrs == [p.data_ptr() for p in m.net.parameters()]
+    before = [p.detach().clone() for p in m.net.parameters()]
+    losses = [step(*batch()).item() for _ in range(3)]
+    assert all(np.isfinite(losses)) and opt._table_key == key
+    assert int(m.model_ema.num_updates.item()) == 8  # 2 warm-up + 6 replays
+    assert any(not torch.equal(a, b) for a, b in zip(before, m.net.parameters()))  # the graph still trains THESE weights
+    m.eval()
+    with m.ema_scope():
+        out2 = DiffusionProcess(args, m.net, (3, 8, 8)).sample(xT)  # replays the first evaluation's graph
+    assert len(m.net._i2r_sampler_graphs) == 1 and not torch.equal(out2, out_swap)
+
+
 def test_slot_path_gradients_vs_oracle():
     """The training step's in-place gradient path -- gradient slots, grouped `affine` products (one launch for all
     blocks, GroupNorm backwards writing d[scale|shift] into its slab), atomically accumulated GroupNorm dgamma/dbeta --
