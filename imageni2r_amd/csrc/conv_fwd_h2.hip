@@ -241,7 +241,9 @@ __device__ __forceinline__ float from_lane_above(float v) {
 //   DPP (3x3, image width a power of two <= 32): only the centre tap column is loaded; the left / right taps are the
 //   neighbouring lanes' values (lane = position along the image row), fetched with DPP wave shifts and zeroed at the
 //   row ends -- a third of the vector-memory instructions and L1/L2 bytes of the plain im2col gather.
-template <int KS, bool SPLIT, int NW, bool DPP>
+// TERMS = 3: the full split product.  TERMS = 1: a_hi*b_hi only -- plain f16 operands, fp32 accumulation (~5e-4 per
+// layer): the optional reduced-precision inference path (set_conv_math("f16")).
+template <int KS, bool SPLIT, int NW, bool DPP, int TERMS = 3>
 __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) {
   constexpr int BM = 128, BN = 32 * NW, NT = 64 * NW;
   constexpr int KC = (KS == 3) ? 48 : 64;
@@ -425,15 +427,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           af[slot][2 * t] = *reinterpret_cast<const half8*>(a_base + t * 32 * ROWL + ks * 32);
-          af[slot][2 * t + 1] = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL + ks * 32);
+          if (TERMS == 3)
+            af[slot][2 * t + 1] = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL + ks * 32);
         }
       };
       auto mfma12 = [&](int ks) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bh[ks], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bl[ks], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t + 1], bh[ks], acc[t], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bl[ks], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t + 1], bh[ks], acc[t], 0, 0, 0);
+          }
         }
       };
       load_frags(0, 0);
@@ -453,9 +458,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
       mfma12(NKS - 1);
       build_frags(nh, nl);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
+      for (int i = 0; i < 4 * TERMS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 6 : 12, 0);  // VALU of the fragment build
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -608,6 +613,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   const int qkv_out = (x_is_split >> 1) & 1;  // flag bit 1: split-pair qkv output for the attention kernel
   const int up_in = (x_is_split >> 2) & 1;    // flag bit 2: x is half resolution, upsampled x2 on the fly
   const int up_res = (x_is_split >> 3) & 1;   // flag bit 3: residual is half resolution, upsampled x2 on the fly
+  const int one_term = (x_is_split >> 4) & 1; // flag bit 4: plain-f16 product where such a kernel is built (3x3, split x, DPP)
   x_is_split &= 1;
   I2R_REQUIRE(!(up_in || up_res) || (H % 2 == 0 && W % 2 == 0), "conv2d_fwd_h2: x2 upsampling needs even H, W");
   I2R_REQUIRE(!up_in || (ksize == 3 && !x2 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP")),
@@ -632,9 +638,9 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);  // two weight stages (hi + lo rows each)
   // DPP tap reuse needs lanes = consecutive positions of one image row: W a power of two <= 32
   const bool dpp = ksize == 3 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP");
-#define H2_LAUNCH(KS_, SP_, NW_, DP_)                                                                              \
+#define H2_LAUNCH(KS_, SP_, NW_, DP_, TM_)                                                                         \
   do {                                                                                                             \
-    auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_>;                                                            \
+    auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_, TM_>;                                                          \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
@@ -643,17 +649,19 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), KS_ == 3 ? lds3 : lds1, s, p);                                  \
   } while (0)
-#define H2_PICK_NW(KS_, SP_, DP_)            \
-  do {                                       \
-    if (bn == 256) H2_LAUNCH(KS_, SP_, 8, DP_); \
-    else H2_LAUNCH(KS_, SP_, 4, DP_);        \
+#define H2_PICK_NW(KS_, SP_, DP_, TM_)            \
+  do {                                            \
+    if (bn == 256) H2_LAUNCH(KS_, SP_, 8, DP_, TM_); \
+    else H2_LAUNCH(KS_, SP_, 4, DP_, TM_);        \
   } while (0)
   if (ksize == 3) {
-    if (x_is_split) { if (dpp) H2_PICK_NW(3, true, true); else H2_PICK_NW(3, true, false); }
-    else { if (dpp) H2_PICK_NW(3, false, true); else H2_PICK_NW(3, false, false); }
+    if (x_is_split) {
+      if (dpp) { if (one_term) H2_PICK_NW(3, true, true, 1); else H2_PICK_NW(3, true, true, 3); }
+      else H2_PICK_NW(3, true, false, 3);
+    } else { if (dpp) H2_PICK_NW(3, false, true, 3); else H2_PICK_NW(3, false, false, 3); }
   } else {
-    if (x_is_split) H2_PICK_NW(1, true, false);
-    else H2_PICK_NW(1, false, false);
+    if (x_is_split) H2_PICK_NW(1, true, false, 3);
+    else H2_PICK_NW(1, false, false, 3);
   }
 #undef H2_PICK_NW
 #undef H2_LAUNCH

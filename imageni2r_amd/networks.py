@@ -107,10 +107,10 @@ class Conv2d(torch.nn.Module):
         pre-split f16-pair output of GroupNorm.forward(split_out=True) (inference, f16x2 conv math only).
         ``out`` (inference f16x2 path only): destination tensor."""
         if x_split and ((self.up and not fuse_up) or self.down or torch.is_grad_enabled()
-                        or ops.conv_math() != "f16x2"):
+                        or not ops.h2_math()):
             raise ValueError("x_split is only valid for a plain inference conv in f16x2 mode")
         if fuse_up:  # inference f16x2, 3x3: the nearest x2 upsample (:79-81) happens in the conv's own addressing
-            if not self.up or torch.is_grad_enabled() or ops.conv_math() != "f16x2":
+            if not self.up or torch.is_grad_enabled() or not ops.h2_math():
                 raise ValueError("fuse_up needs an up=True conv in f16x2 inference")
             return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
                                      None if residual is None else ops._c(residual), x_split, out, False, True, up_res)
@@ -122,7 +122,7 @@ class Conv2d(torch.nn.Module):
         if self.down:
             x = ops.Down2Fn.apply(x)
         if self.weight is not None:
-            if not torch.is_grad_enabled() and ops.conv_math() == "f16x2":
+            if not torch.is_grad_enabled() and ops.h2_math():
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
                                          None if residual is None else ops._c(residual), x_split, out, qkv_out,
                                          False, up_res)
@@ -203,7 +203,7 @@ class UNetBlock(torch.nn.Module):
         ``params``: this block's ``affine(emb)`` when the network computed all of them in one grouped launch."""
         orig = x
         # inference in f16x2 conv math: the norms hand the convs pre-split f16 pairs (no conversion in the conv)
-        sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
+        sp = (not torch.is_grad_enabled()) and ops.h2_math()
         # up blocks in that mode: the x2 upsample of conv0's input and of the weight-less skip never hit memory
         fu = (sp and self.conv0.up and self.skip is not None and self.skip.weight is None and not isinstance(x, tuple)
               and x.shape[3] * 2 <= 32 and (x.shape[3] & (x.shape[3] - 1)) == 0
@@ -372,7 +372,7 @@ class DhariwalUNet(torch.nn.Module):
         """Inference in f16x2 mode, geometry the dual-source kernels cover (H*W a power of two >= 4, C1 % 16 == 0,
         a 1x1 skip conv): the decoder concat (:458) is not materialised."""
         hw = x.shape[2] * x.shape[3]
-        return ((not torch.is_grad_enabled()) and ops.conv_math() == "f16x2" and hw >= 4 and (hw & (hw - 1)) == 0
+        return ((not torch.is_grad_enabled()) and ops.h2_math() and hw >= 4 and (hw & (hw - 1)) == 0
                 and x.shape[1] % 16 == 0 and block.skip is not None and block.skip.weight is not None
                 and block.skip.weight.shape[-1] == 1 and not (block.conv0.up or block.conv0.down)
                 and (x.shape[1] + skip.shape[1]) // block.norm0.num_groups * hw <= 16384)
@@ -422,7 +422,7 @@ class DhariwalUNet(torch.nn.Module):
                 else:
                     x = ops.ConcatFn.apply(x, skip)
             x = block(x, emb, None if ss is None else ss[block])
-        sp = (not torch.is_grad_enabled()) and ops.conv_math() == "f16x2"
+        sp = (not torch.is_grad_enabled()) and ops.h2_math()
         return self.out_conv(self.out_norm(x, act_silu=True, split_out=sp), x_split=sp)
 
 

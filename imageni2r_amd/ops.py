@@ -41,17 +41,26 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 _PACK_EPOCH = [0]
-_CONV_MATH = ["f16x2"]  # math of INFERENCE (no-grad) conv forwards: "f16x2" (split-f16 MFMA) or "f32" (exact fp32 MFMA)
+_CONV_MATH = ["f16x2"]  # math of INFERENCE (no-grad) conv forwards: "f16x2" (split-f16 MFMA), "f32" (exact fp32 MFMA)
+                        # or "f16" (f16x2 with the 3x3 convs reduced to the plain f16 product; optional, 1e-2 class)
 
 
 def conv_math() -> str:
     return _CONV_MATH[0]
 
 
+def h2_math() -> bool:
+    """True when inference convs / attention run on the half-precision matrix cores ("f16x2" or "f16")."""
+    return _CONV_MATH[0] in ("f16x2", "f16")
+
+
 def set_conv_math(mode: str) -> None:
-    """Select the inference conv kernel: "f16x2" (default; ~1e-6 rel. error, 3-5x faster) or "f32" (exact fp32 MFMA).
+    """Select the inference conv kernel: "f16x2" (default; ~1e-6 rel. error, 3-5x faster than fp32 MFMA), "f32" (exact
+    fp32 MFMA) or "f16" -- the optional reduced-precision path (north_star's "bf16-MFMA path", built on f16 for its three
+    extra significand bits at the same matrix rate): as "f16x2", but the 3x3 convs multiply the f16 high halves only
+    (one MFMA instead of three, ~5e-4 per layer; the whole denoiser stays inside 1e-2).
     Training (grad-enabled) forwards/backwards always use the exact fp32 kernels."""
-    if mode not in ("f16x2", "f32"):
+    if mode not in ("f16x2", "f32", "f16"):
         raise ValueError(mode)
     _CONV_MATH[0] = mode
 
@@ -219,7 +228,8 @@ def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=N
             raise ValueError(f"conv2d_fwd_h2: residual shape {tuple(residual.shape)} != {want}")
     nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cin, H, W, Cout, k)
     ws = torch.empty((nsk,), dtype=torch.float32, device=x.device) if nsk > 0 else None
-    flags = int(bool(x_split)) | (2 if qkv_out else 0) | (4 if up_in else 0) | (8 if up_res else 0)
+    flags = (int(bool(x_split)) | (2 if qkv_out else 0) | (4 if up_in else 0) | (8 if up_res else 0)
+             | (16 if _CONV_MATH[0] == "f16" else 0))
     _lib.call("i2r_conv2d_fwd_h2", _p(x), _p(wp), _p(bias), _p(residual), _p(out), _p(ws), nsk, B, Cin, H, W, Cout, k,
               flags, _stream())
     return out
@@ -373,7 +383,7 @@ def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, s
 
 def attention_h2_ok(T) -> bool:
     """Shapes the f16x2 inference attention kernel covers (others take the fp32 kernels)."""
-    return conv_math() == "f16x2" and T > 32 and T % 32 == 0
+    return h2_math() and T > 32 and T % 32 == 0
 
 
 def attention_fwd(qkv, heads, save_lse=False, presplit=False):

@@ -72,7 +72,11 @@ long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksi
 /* x_is_split is a flag word.  Bit 0: the activations were already split by their producer (i2r_groupnorm_fwd_f32 with
  * split_out): each 32-bit element holds f16 hi | f16 lo << 16 in the same NCHW positions.  Bit 1: the OUTPUT is the qkv
  * tensor of an attention block and is stored in that split form, q rows (channel % 3 == 0) pre-multiplied by the softmax
- * scale, for i2r_attention_fwd_h2 with presplit = 1; needs Cout % 3 == 0, and split-K is not used for it. */
+ * scale, for i2r_attention_fwd_h2 with presplit = 1; needs Cout % 3 == 0, and split-K is not used for it.
+ * Bit 2 (3x3, W a power of two <= 32): x is (B, Cin, H/2, W/2) and is nearest-upsampled x2 while it is read (Conv2d
+ * up=True, networks.py:79-81).  Bit 3: the residual is (B, Cout, H/2, W/2), upsampled the same way; no split-K.
+ * Bit 4: reduced precision (optional, 1e-2 class): where a kernel is built for it (3x3, bit 0 set, W a power of two
+ * <= 32) only the f16 high halves are multiplied -- one MFMA per tile-step instead of three; ignored elsewhere. */
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       int x_is_split, i2r_stream_t stream);

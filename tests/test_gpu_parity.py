@@ -345,6 +345,27 @@ def test_denoiser_golden(tiny_gpu):
         assert rel_err(D2.cpu().numpy(), g["D_scalar_sigma"]) < TOL
 
 
+def test_denoiser_and_sampler_golden_f16_option(tiny_gpu):
+    """The optional reduced-precision inference path (north_star: 1e-2): denoiser output and the 18-step sampler
+    against the same reference vectors as the default path."""
+    import imageni2r_amd
+    from imageni2r_amd import DiffusionProcess
+    g, g5 = load_golden("g4_net.npz"), load_golden("g5_sampler.npz")
+    imageni2r_amd.set_conv_math("f16")
+    try:
+        with torch.no_grad():
+            D = tiny_gpu.net(cu(g["x"]), cu(g["sigma"]))
+        e = rel_err(D.cpu().numpy(), g["D_per_sample"])
+        assert TOL * 1e-2 < e < 1e-2, e
+        out = DiffusionProcess(tiny_args(device=DEV), tiny_gpu.net, (3, 8, 8), use_graph=False).sample(
+            torch.from_numpy(g5["xT"]))
+        assert rel_err(out.cpu().numpy(), g5["out"]) < 1e-2
+    finally:
+        imageni2r_amd.set_conv_math("f16x2")
+    with torch.no_grad():  # and the default path is back
+        assert rel_err(tiny_gpu.net(cu(g["x"]), cu(g["sigma"])).cpu().numpy(), g["D_per_sample"]) < TOL
+
+
 def test_loss_and_gradients_golden(tiny_gpu):
     g = load_golden("g4_net.npz")
     m = tiny_gpu

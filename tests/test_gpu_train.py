@@ -125,6 +125,40 @@ def test_groupnorm_split_out_feeds_split_conv(ops, B, Cin, Cout, H, k):
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H", [(3, 128, 128, 16), (5, 96, 160, 4), (2, 1024, 512, 2), (2, 128, 12, 16),
+                                          (260, 128, 256, 16), (2, 64, 128, 32)])
+def test_conv_f16_single_term_path(ops, B, Cin, Cout, H):
+    """set_conv_math("f16"), the optional reduced-precision path: the 3x3 conv on pre-split activations multiplies the
+    f16 high halves only.  It computes exactly that product (checked against an fp64 conv of the rounded operands) and
+    stays far inside the 1e-2 bar against the unrounded one; the default mode is untouched."""
+    import imageni2r_amd
+    gen = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=gen) * 2.0 + 0.5
+    gw, gb = torch.randn(Cin, generator=gen), torch.randn(Cin, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, H, generator=gen)
+    G = min(32, Cin // 4)
+    n = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double(), G, gw.double(), gb.double(), 1e-5))
+    ref = torch.nn.functional.conv2d(n, w.double(), b.double(), padding=1) + res.double()
+    ysp, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True, split_out=True)
+    wp = ops.conv2d_pack_h2(cu(w.numpy()))
+    full = ops.conv2d_fwd_h2(ysp, tuple(w.shape), wp, cu(b.numpy()), cu(res.numpy()), x_split=True)
+    imageni2r_amd.set_conv_math("f16")
+    try:
+        y = ops.conv2d_fwd_h2(ysp, tuple(w.shape), wp, cu(b.numpy()), cu(res.numpy()), x_split=True)
+    finally:
+        imageni2r_amd.set_conv_math("f16x2")
+    assert rel_err(full.cpu().numpy(), ref.numpy()) < 5e-6
+    e = rel_err(y.cpu().numpy(), ref.numpy())
+    assert 1e-6 < e < 2e-3, e  # really the reduced product, and well inside 1e-2
+    # the rounded operands: hi halves as the GroupNorm kernel stored them, weights as packed (scaled by 64, see the kernel)
+    x_hi = (ysp.view(torch.int32) & 0xFFFF).to(torch.int16).view(torch.float16).double().cpu()
+    w_hi = (w * 64.0).half().double() / 64.0
+    ref_hi = torch.nn.functional.conv2d(x_hi, w_hi, b.double(), padding=1) + res.double()
+    assert rel_err(y.cpu().numpy(), ref_hi.numpy()) < 2e-6
+
+
 @pytest.mark.parametrize("B,heads,H", [(2, 2, 16), (1, 4, 32), (3, 4, 8), (2, 8, 8), (1, 2, 8)])
 def test_attention_split_f16_vs_oracle(ops, B, heads, H):
     """Inference attention on the f16 matrix cores (T = 64, 256, 1024; several key tiles, base-2 online softmax)."""
