@@ -251,10 +251,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
   constexpr int ROWL = KC * 2 + 16;        // LDS row bytes (odd multiple of 16 B -> conflict-free b128 rows)
   constexpr int RB = 2 * KC * 2;           // global bytes per packed weight row (hi | lo)
   constexpr int PPR = RB / 16;             // 16-B pieces per weight row
-  constexpr int NA = BM * PPR / NT;        // weight pieces per thread per chunk
+  constexpr int PPRL = (TERMS == 3) ? PPR : PPR / 2;  // pieces of a row that are fetched (single-term: the hi half only)
+  constexpr int NA = (BM * PPRL + NT - 1) / NT;       // weight pieces per thread per chunk
   constexpr int ABUF = 2 * BM * ROWL;      // bytes of one weight stage (hi rows, then lo rows)
   constexpr int NRAW = (KS == 3 && DPP) ? 1 : NKS;  // raw activation register sets per chunk
-  static_assert(BM * PPR % NT == 0, "weight tile must divide over the threads");
+  static_assert(TERMS == 1 || BM * PPR % NT == 0, "weight tile must divide over the threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,10 +280,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     int idx = tid + NT * j;
-    int row = idx / PPR, piece = idx % PPR;
-    voffA[j] = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * RB + piece * 16) : OOR;
+    const bool used = idx < BM * PPRL;  // single-term, 8 waves: 1.5 pieces per thread -- the spare half-slot loads
+    int row = idx / PPRL, piece = idx % PPRL;  // nothing (out of range) and parks its zeros in a row's padding
+    voffA[j] = (used && m0 + row < p.Cout) ? (unsigned)((m0 + row) * RB + piece * 16) : OOR;
     int lo = piece >= PPR / 2;
-    ldsA[j] = (lo ? BM * ROWL : 0) + row * ROWL + (piece - lo * (PPR / 2)) * 16;
+    ldsA[j] = used ? (lo ? BM * ROWL : 0) + row * ROWL + (piece - lo * (PPR / 2)) * 16 : (idx % BM) * ROWL + KC * 2;
   }
   const unsigned stepA = (unsigned)p.Cout * RB;  // bytes per chunk of packed weights
 
