@@ -50,6 +50,9 @@ class DiffusionProcess:
         self._graphs = self.net.__dict__.setdefault("_i2r_sampler_graphs", {})
         self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
         self._streams = None
+        # series per captured loop: bigger requests are sampled in pieces (every activation of a piece has to stay
+        # under the conv kernels' 2 GiB buffer-addressing limit).  None = 4096 at 16x16 images, scaled with the area.
+        self.max_graph_batch = int(os.environ["I2R_MAX_GRAPH_BATCH"]) if "I2R_MAX_GRAPH_BATCH" in os.environ else None
 
     # ------------------------------------------------------------------------------------------------------
     def _t_steps(self):
@@ -117,29 +120,40 @@ class DiffusionProcess:
             if not self.use_graph:
                 sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
                 return self._loop(latents, t_host, sig_dev)
+            cap = self.max_graph_batch or max(1, 4096 * 256 // (latents.shape[-1] * latents.shape[-2]))
+            dual = lambda m: bool(self.dual_stream_min) and m >= self.dual_stream_min and m % 2 == 0  # noqa: E731
             n = latents.shape[0]
-            if self.dual_stream_min and n >= self.dual_stream_min and n % 2 == 0:
-                # Two half-batch graphs replayed side by side on two streams: the HBM-bound kernels of one half
-                # (GroupNorm, 1x1 convs) run beside the matrix-core-bound 3x3 convs of the other (+2-3 % series/s).
-                parts = latents.chunk(2)
-                entries = [self._graph_entry(p, t_steps, t_host, slot=i) for i, p in enumerate(parts)]
-                if self._streams is None:
-                    self._streams = [torch.cuda.Stream(device=latents.device) for _ in range(2)]
-                cur = torch.cuda.current_stream()
-                for st, (graph, static_in, _, _), p in zip(self._streams, entries, parts):
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        static_in.copy_(p)
-                        graph.replay()
-                for st in self._streams:
-                    cur.wait_stream(st)
-                return torch.cat([e[2] for e in entries])
-            graph, static_in, static_out, _ = self._graph_entry(latents, t_steps, t_host)
-            static_in.copy_(latents)
-            graph.replay()
-            return static_out.clone()
+            if n > (2 * cap if dual(n) else cap):
+                # bulk generation (BASELINE config E): pieces of the largest size one replay can take, one after the other
+                piece = 2 * cap if dual(2 * cap) else cap
+                return torch.cat([self._sample_piece(latents[i:i + piece], t_steps, t_host, dual)
+                                  for i in range(0, n, piece)])
+            return self._sample_piece(latents, t_steps, t_host, dual)
         finally:
             self.net.train(was_training)
+
+    def _sample_piece(self, latents, t_steps, t_host, dual):
+        n = latents.shape[0]
+        if dual(n):
+            # Two half-batch graphs replayed side by side on two streams: the HBM-bound kernels of one half
+            # (GroupNorm, 1x1 convs) run beside the matrix-core-bound 3x3 convs of the other (+2-3 % series/s).
+            parts = latents.chunk(2)
+            entries = [self._graph_entry(p, t_steps, t_host, slot=i) for i, p in enumerate(parts)]
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=latents.device) for _ in range(2)]
+            cur = torch.cuda.current_stream()
+            for st, (graph, static_in, _, _), p in zip(self._streams, entries, parts):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    static_in.copy_(p)
+                    graph.replay()
+            for st in self._streams:
+                cur.wait_stream(st)
+            return torch.cat([e[2] for e in entries])
+        graph, static_in, static_out, _ = self._graph_entry(latents, t_steps, t_host)
+        static_in.copy_(latents)
+        graph.replay()
+        return static_out.clone()
 
     @torch.no_grad()
     def sampling(self, sampling_number=16, impute=False, xT=None):

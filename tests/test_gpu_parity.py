@@ -465,6 +465,24 @@ def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
     assert rel_err(two.sample(torch.from_numpy(g["xT"])).cpu().numpy(), g["out"]) < TOL
 
 
+def test_sampler_bulk_request_is_sampled_in_pieces(tiny_gpu):
+    """BASELINE config E (bulk generation): a request above what one replay may hold (the kernels' 2 GiB addressing
+    limit) is cut into pieces sampled one after the other -- same series, in order, ragged tail included."""
+    from imageni2r_amd import DiffusionProcess
+    args = tiny_args(device=DEV)
+    xT = torch.randn(11, 3, 8, 8, generator=torch.Generator().manual_seed(9))
+    one = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8))
+    one.dual_stream_min = 0
+    ref = one.sample(xT)
+    for dual_min, cap in ((4, 2), (0, 3), (6, 4)):
+        proc = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8))
+        proc.dual_stream_min, proc.max_graph_batch = dual_min, cap
+        out = proc.sample(xT)
+        assert out.dtype == torch.float64 and tuple(out.shape) == (11, 3, 8, 8)
+        assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (dual_min, cap)
+    assert max(k[0][0] for k in tiny_gpu.net._i2r_sampler_graphs if k[0][1:] == (3, 8, 8)) == 11  # only `one` took all 11
+
+
 def test_ema_scope_swap_samples_with_ema_weights_and_reuses_graphs(monkeypatch):
     """run_irregular.py:250-259: a new DiffusionProcess per evaluation inside ``ema_scope``.  The pointer-swapped scope
     gives the same series as the reference's copy sequence, the second evaluation replays the first one's graph, and
