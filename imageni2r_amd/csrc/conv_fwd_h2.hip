@@ -5,8 +5,8 @@
 //        a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi     (+ a_lo*b_lo ~ 2^-22 |ab|, dropped)
 // i.e. THREE v_mfma_f32_32x32x16_f16 (32 cycles each for a 32x32x16 tile-step) replace EIGHT v_mfma_f32_32x32x2_f32
 // (64 cycles each): 5.3x the matrix throughput of the exact-fp32 kernel (conv_fwd.hip) at ~1e-6 relative error,
-// far inside the 1e-4 bar of the path.  Used for inference (the sampler's 35 denoiser evaluations per series);
-// training keeps the exact fp32 kernels because gradients can underflow fp16's range.
+// far inside the 1e-4 bar of the path.  Used for inference (the sampler's 35 denoiser evaluations per series) and for
+// the larger training forwards; the backward keeps the exact fp32 kernels because gradients can underflow fp16's range.
 //
 // Range: activations must satisfy |x| < 65504 (fp16 max); weights are pre-scaled by 2^6 when packed (so that the lo
 // halves of ~1/sqrt(fan_in) weights stay normal fp16 numbers) and the epilogue multiplies by 2^-6 (exact).

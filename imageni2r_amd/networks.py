@@ -126,6 +126,9 @@ class Conv2d(torch.nn.Module):
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
                                          None if residual is None else ops._c(residual), x_split, out, qkv_out,
                                          False, up_res)
+            if torch.is_grad_enabled() and ops.train_fwd_h2(x.shape[0] * x.shape[2] * x.shape[3]):
+                return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, None, self.packed_weight_dgrad(),
+                                          self.packed_weight_h2())
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -330,12 +333,14 @@ class DhariwalUNet(torch.nn.Module):
         for i, mod in enumerate(m for m in self.modules() if isinstance(m, GroupNorm)):
             mod._rng_id = i + 1
 
-    def pack_all_weights(self, dgrad=True):
-        """Pack every conv weight (forward layout, and the data-gradient layout when ``dgrad``) in ONE launch into
-        persistent buffers and mark them current, so the following forward/backward launches no per-layer pack
-        kernels.  Call once per optimiser step (GraphedTrainStep does, inside its graph)."""
+    def _pack_plan(self, dgrad=True):
+        """Host side of pack_all_weights: the job list, destination views, pointer table and block map (cached while
+        the weights stay where they are).  None when there is nothing to pack.  Launches nothing."""
         convs = [m for m in self.modules() if isinstance(m, Conv2d) and m.weight is not None]
-        key = (tuple(c.weight.data_ptr() for c in convs), bool(dgrad))
+        fwd_too = not ops.train_fwd_h2()  # every forward on the f16x2 kernel: only the data-gradient layout is fp32
+        if not (fwd_too or dgrad):
+            return None
+        key = (tuple(c.weight.data_ptr() for c in convs), bool(dgrad), fwd_too)
         ps = getattr(self, "_packset", None)
         if ps is None or ps[0] != key:
             dev = convs[0].weight.device
@@ -343,7 +348,7 @@ class DhariwalUNet(torch.nn.Module):
             jobs = []
             for c in convs:
                 Cout, Cin, k, _ = c.weight.shape
-                for dg in ((0, 1) if dgrad else (0,)):
+                for dg in ([0] if fwd_too else []) + ([1] if dgrad else []):
                     jobs.append((c, dg, ops._lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, dg)))
             pool = torch.empty(sum((n + 3) // 4 * 4 for _, _, n in jobs), dtype=torch.float32, device=dev)
             rows, bmap, views, off = [], [], [], 0
@@ -358,6 +363,15 @@ class DhariwalUNet(torch.nn.Module):
             bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
             ps = (key, jobs, views, table, bmap_t, len(bmap), pool)
             self._packset = ps
+        return ps
+
+    def pack_all_weights(self, dgrad=True):
+        """Pack every conv weight (forward layout, and the data-gradient layout when ``dgrad``) in ONE launch into
+        persistent buffers and mark them current, so the following forward/backward launches no per-layer pack
+        kernels.  Call once per optimiser step (GraphedTrainStep does, inside its graph)."""
+        ps = self._pack_plan(dgrad)
+        if ps is None:
+            return
         _, jobs, views, table, bmap_t, nblocks, _ = ps
         ops.pack_multi(table, bmap_t, nblocks)
         for (c, dg, _), v in zip(jobs, views):

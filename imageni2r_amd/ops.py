@@ -6,6 +6,7 @@ libi2r_hip.so.  All wrappers validate on the host (device, dtype, contiguity, sh
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -59,10 +60,36 @@ def set_conv_math(mode: str) -> None:
     fp32 MFMA) or "f16" -- the optional reduced-precision path (north_star's "bf16-MFMA path", built on f16 for its three
     extra significand bits at the same matrix rate): as "f16x2", but the 3x3 convs multiply the f16 high halves only
     (one MFMA instead of three, ~5e-4 per layer; the whole denoiser stays inside 1e-2).
-    Training (grad-enabled) forwards/backwards always use the exact fp32 kernels."""
+    Training: the backward always uses the exact fp32 kernels; the forward of convs with >= 2048 output positions runs
+    on the f16x2 kernel unless the mode is "f32" (set_train_fwd_h2 / I2R_TRAIN_FWD_H2; never the "f16" product)."""
     if mode not in ("f16x2", "f32", "f16"):
         raise ValueError(mode)
     _CONV_MATH[0] = mode
+
+
+# Training forwards of the convs on the f16x2-split kernels (backward always uses the exact fp32 kernels):
+# "auto" = convs with at least _TRAIN_FWD_H2_MINPOS output positions (below that the per-layer weight split costs more
+# than the faster kernel saves), "1" = all, "0" = none.
+_TRAIN_FWD_H2 = [os.environ.get("I2R_TRAIN_FWD_H2", "auto")]
+_TRAIN_FWD_H2_MINPOS = [int(os.environ.get("I2R_TRAIN_FWD_H2_MINPOS", 2048))]
+
+
+def train_fwd_h2(npos=None) -> bool:
+    """Does a training conv forward with ``npos`` output positions (None: "every conv?") run on the f16x2 kernel?"""
+    mode = _TRAIN_FWD_H2[0]
+    if not h2_math() or mode == "0":
+        return False
+    if mode == "1":
+        return True
+    return npos is not None and npos >= _TRAIN_FWD_H2_MINPOS[0]
+
+
+def set_train_fwd_h2(mode) -> None:
+    """"auto" (default), True / "1" (every conv) or False / "0" (exact fp32 forward everywhere)."""
+    mode = {True: "1", False: "0"}.get(mode, mode)
+    if mode not in ("auto", "0", "1"):
+        raise ValueError(mode)
+    _TRAIN_FWD_H2[0] = mode
 
 
 _RNG_STEP = [None]  # device uint64 step counter of the training RNG streams (set by GraphedTrainStep), or None
@@ -562,12 +589,14 @@ class Conv2dFn(torch.autograd.Function):
     """conv2d + bias + residual (networks.py:87-89 and the x.add_ of :178/:185)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, wp=None, wpd=None):
+    def forward(ctx, x, w, bias, residual, wp=None, wpd=None, wph=None):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.wpd = wpd  # weights already packed for the data gradient (DhariwalUNet.pack_all_weights), or None
         ctx.slots = (getattr(w, "_grad_slot", None), getattr(bias, "_grad_slot", None))
+        if wph is not None:  # forward on the f16x2-split kernel (~1e-6); the gradients below use the exact kernels
+            return conv2d_fwd_h2(x, tuple(w.shape), wph, bias, None if residual is None else _c(residual))
         return conv2d_fwd(x, w, bias, None if residual is None else _c(residual), wp)
 
     @staticmethod
@@ -584,7 +613,7 @@ class Conv2dFn(torch.autograd.Function):
                                   db=sb.detach() if (use and ctx.has_bias) else None,
                                   accumulate=use and slots_zeroed())
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
 class Down2Fn(torch.autograd.Function):

@@ -366,7 +366,20 @@ def test_denoiser_and_sampler_golden_f16_option(tiny_gpu):
         assert rel_err(tiny_gpu.net(cu(g["x"]), cu(g["sigma"])).cpu().numpy(), g["D_per_sample"]) < TOL
 
 
-def test_loss_and_gradients_golden(tiny_gpu):
+@pytest.fixture(params=["0", "1"], ids=["fwd_f32", "fwd_f16x2"])
+def train_fwd(request):
+    """Training conv forwards on the exact fp32 kernels and on the f16x2-split kernels (what "auto" picks for convs
+    with >= 2048 positions; the tiny net is below that, so the mode is forced here).  Same 1e-4 bar for both."""
+    from imageni2r_amd import ops
+    before = ops._TRAIN_FWD_H2[0]
+    ops.set_train_fwd_h2(request.param)
+    ops.new_pack_epoch()
+    yield request.param
+    ops.set_train_fwd_h2(before)
+    ops.new_pack_epoch()
+
+
+def test_loss_and_gradients_golden(tiny_gpu, train_fwd):
     g = load_golden("g4_net.npz")
     m = tiny_gpu
     m.zero_grad()
@@ -398,7 +411,7 @@ def test_loss_and_gradients_golden(tiny_gpu):
         m.zero_grad()
 
 
-def test_full_gradients_vs_oracle(tiny_gpu):
+def test_full_gradients_vs_oracle(tiny_gpu, train_fwd):
     """Every parameter gradient, element by element, against the oracle's autograd on the same inputs."""
     g = load_golden("g4_net.npz")
     m = tiny_gpu
