@@ -271,22 +271,27 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
 #pragma unroll
     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    // the kernel is VALU-bound (profiles/r01_pmc_attention_T1024.txt): the bare v_exp_f32 is enough here -- every
+    // argument is <= 0, and a result below 2^-126 may flush to 0 -- where exp2f() expands to ~6 instructions
     float m_new = fmaxf(m_run, mt);
-    float alpha = exp2f(m_run - m_new);
+    float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.0f;
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pv[r] = exp2f(sacc[r] - m_new);
+      pv[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new);
       psum += pv[r];
     }
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    // after the first tiles the running maximum rarely moves: skip the 32 multiplies by 1 (wave-uniform branch)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+    }
     // ---- O += V P
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
