@@ -158,6 +158,23 @@ __device__ __forceinline__ void a_split8(const float* v, ah8& hi, ah8& lo) {
   }
 }
 
+// hi/lo split of softmax weights (plain fp32 values in [0, 1], not products: the double-rounding trap f16_split()
+// guards against cannot occur), two elements per conversion instruction (v_cvt_pk_f16_f32, round to nearest)
+typedef float af2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ah2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void p_split8(const float* v, ah8& hi, ah8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    af2 x = {v[2 * i], v[2 * i + 1]};
+    ah2 h2 = __builtin_convertvector(x, ah2);
+    af2 r = x - __builtin_convertvector(h2, af2);
+    ah2 l2 = __builtin_convertvector(r, ah2);
+    _Float16 h0 = h2.x, h1 = h2.y, l0 = l2.x, l1 = l2.y;
+    hi[2 * i] = h0; hi[2 * i + 1] = h1;
+    lo[2 * i] = l0; lo[2 * i + 1] = l1;
+  }
+}
+
 #define AKROW 144  // bytes per key row of the K image: 64 d x 2 B + 16 pad (odd multiple of 16 B)
 #define AVROW 80   // bytes per channel row of the V image: 32 keys x 2 B + 16 pad
 
@@ -177,7 +194,7 @@ __device__ __forceinline__ void a_unpack8(const float* v, ah8& hi, ah8& lo) {
 
 // PRE: qkv arrives pre-split (and q pre-scaled) from i2r_conv2d_fwd_h2's qkv output mode.
 template <int QW, bool PRE>
-__global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(64 * QW, QW == 4 ? 3 : QW) void attn_fwd_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int heads, int T) {
   constexpr int NT = 64 * QW, NIT = 256 / NT;                 // staging work items per thread
   constexpr int KBYTES = KT * AKROW, VBYTES = HD * AVROW;     // one of hi / lo
@@ -210,20 +227,31 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
     for (int r = 0; r < 16; ++r) O[t][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
 
-  // staging: item = (key, d-group of 8) for K; (channel, piece = k-step s2, half h2) for V
+  // staging: item = (key, d-group of 8) for K; (channel, piece = k-step s2, half h2) for V.  Loads go through a
+  // buffer descriptor over this head's 192 x T slab: per-thread byte offsets are loop invariant, the key tile advances
+  // through the scalar offset -- no 64-bit address arithmetic in the loop (it was ~40 % of the loop's VALU work).
+  __amdgpu_buffer_rsrc_t rQKV = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * HD * T * 4, 0x00020000);
+  unsigned voffK[NIT][8], voffV[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int item = tid + NT * it;
+    int key = item & 31, dg = item >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) voffK[it][j] = (unsigned)(((3 * (8 * dg + j) + 1) * T + key) * 4);
+    int c = item >> 2, piece = item & 3, s2 = piece >> 1, h2 = piece & 1;
+    voffV[it] = (unsigned)(((3 * c + 2) * T + 16 * s2 + 4 * h2) * 4);
+  }
   float kreg[NIT][8];
   float4 vreg[NIT][2];
   auto stage_load = [&](int k0) {
+    const unsigned soff = (unsigned)k0 * 4;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      int item = tid + NT * it;
-      int key = item & 31, dg = item >> 5;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kreg[it][j] = base[(long)(3 * (8 * dg + j) + 1) * T + k0 + key];
-      int c = item >> 2, piece = item & 3, s2 = piece >> 1, h2 = piece & 1;
-      const float* vp = base + (long)(3 * c + 2) * T + k0 + 16 * s2 + 4 * h2;
-      vreg[it][0] = *reinterpret_cast<const float4*>(vp);
-      vreg[it][1] = *reinterpret_cast<const float4*>(vp + 8);
+      for (int j = 0; j < 8; ++j)
+        kreg[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rQKV, voffK[it][j], soff, 0));
+      vreg[it][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rQKV, voffV[it], soff, 0));
+      vreg[it][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rQKV, voffV[it] + 32, soff, 0));
     }
   };
   auto stage_store = [&](int buf) {
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_h2_kernel(const float* __res
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       ah8 ph, pl;
-      a_split8(pv + 8 * s, ph, pl);
+      p_split8(pv + 8 * s, ph, pl);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const unsigned char* vrow = st + 2 * KBYTES + (t * 32 + l31) * AVROW + (2 * s + h) * 16;
