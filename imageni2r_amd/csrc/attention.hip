@@ -408,7 +408,7 @@ __global__ void attn_delta_kernel(const float* __restrict__ out, const float* __
 }
 
 template <int QW>
-__global__ __launch_bounds__(64 * QW) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
                                                                const float* __restrict__ dout,
