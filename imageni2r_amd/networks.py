@@ -12,8 +12,6 @@ from __future__ import annotations
 
 import itertools
 
-import os
-
 import numpy as np
 import torch
 
@@ -210,11 +208,11 @@ class UNetBlock(torch.nn.Module):
         # up blocks in that mode: the x2 upsample of conv0's input and of the weight-less skip never hit memory
         fu = (sp and self.conv0.up and self.skip is not None and self.skip.weight is None and not isinstance(x, tuple)
               and x.shape[3] * 2 <= 32 and (x.shape[3] & (x.shape[3] - 1)) == 0
-              and not os.environ.get("I2R_NO_FUSE_UP"))
+              and not ops.knob("no_fuse_up"))
         sp0 = sp and (fu or not (self.conv0.up or self.conv0.down))
         # training: the residual / skip branch leaves through norm0's bypass output, so x has one consumer and its two
         # gradients are summed inside the GroupNorm backward kernel instead of by an autograd accumulation kernel
-        byp = torch.is_grad_enabled() and not isinstance(x, tuple) and not os.environ.get("I2R_NO_GN_BYPASS")
+        byp = torch.is_grad_enabled() and not isinstance(x, tuple) and not ops.knob("no_gn_bypass")
         if byp:
             h0, orig = self.norm0(x, act_silu=True, bypass=True)
         else:
@@ -247,18 +245,18 @@ class UNetBlock(torch.nn.Module):
         """norm2 -> qkv conv -> attention.  In f16x2 inference the qkv conv writes split pairs (q pre-scaled) and the
         attention kernel only permutes them into fragments."""
         if sp:
-            pre = ops.attention_h2_ok(x.shape[2] * x.shape[3]) and not os.environ.get("I2R_NO_QKV_PRESPLIT")
+            pre = ops.attention_h2_ok(x.shape[2] * x.shape[3]) and not ops.knob("no_qkv_presplit")
             qkv = self.qkv(self.norm2(x, split_out=True), x_split=True, qkv_out=pre)
             return ops.attention_fwd(qkv, self.num_heads, presplit=pre)[0]
         return ops.AttentionFn.apply(self.qkv(self.norm2(x)), self.num_heads)
 
-    ATTN_CHUNK_BYTES = float(os.environ.get("I2R_ATTN_CHUNK_MB", 256)) * 1e6  # qkv bytes per chunk of the chunked attention tail (0 disables chunking)
-
     def _attn_chunk(self, x):
+        """Samples per chunk of the chunked attention tail (knob "attn_chunk_bytes" of qkv per chunk; 0 disables)."""
         per_sample = 3 * x.shape[1] * x.shape[2] * x.shape[3] * 4
-        if not self.ATTN_CHUNK_BYTES:
+        budget = ops.knob("attn_chunk_bytes")
+        if not budget:
             return 0
-        chunk = 1 << max(0, int(self.ATTN_CHUNK_BYTES // per_sample).bit_length() - 1)
+        chunk = 1 << max(0, int(budget // per_sample).bit_length() - 1)
         return chunk if x.shape[0] >= 2 * chunk else 0
 
 

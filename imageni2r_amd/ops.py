@@ -67,6 +67,31 @@ def set_conv_math(mode: str) -> None:
     _CONV_MATH[0] = mode
 
 
+# Kernel-selection knobs, read from the environment ONCE at import (A/B switches for measurements; the defaults are the
+# product path).  They are part of every captured graph's cache key (kernel_mode_key).
+_KNOBS = {
+    "no_fuse_up": bool(os.environ.get("I2R_NO_FUSE_UP")),            # materialise the decoder's x2 upsample
+    "no_gn_bypass": bool(os.environ.get("I2R_NO_GN_BYPASS")),        # training: residual branch outside GroupNorm
+    "no_qkv_presplit": bool(os.environ.get("I2R_NO_QKV_PRESPLIT")),  # attention splits q,k,v itself
+    "attn_chunk_bytes": float(os.environ.get("I2R_ATTN_CHUNK_MB", 256)) * 1e6,  # qkv bytes per attention-tail chunk
+}
+
+
+def knob(name):
+    return _KNOBS[name]
+
+
+def set_knob(name, value) -> None:
+    if name not in _KNOBS:
+        raise KeyError(name)
+    _KNOBS[name] = value
+
+
+def kernel_mode_key():
+    """Everything that changes WHICH kernels an inference pass launches (for graph cache keys)."""
+    return (_CONV_MATH[0],) + tuple(sorted(_KNOBS.items()))
+
+
 # Training forwards of the convs on the f16x2-split kernels (backward always uses the exact fp32 kernels):
 # "auto" = convs with at least _TRAIN_FWD_H2_MINPOS output positions (below that the per-layer weight split costs more
 # than the faster kernel saves), "1" = all, "0" = none.

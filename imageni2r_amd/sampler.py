@@ -102,8 +102,9 @@ class DiffusionProcess:
         return entry
 
     def _graph_key(self, latents):
+        # the kernel-selection switches are part of the key: a graph replays the kernels it was captured with
         return (tuple(latents.shape), latents.device.index,
-                hash(tuple(p.data_ptr() for p in self.net.parameters())))
+                hash(tuple(p.data_ptr() for p in self.net.parameters())), ops.kernel_mode_key())
 
     @torch.no_grad()
     def sample(self, latents, class_labels=None):
@@ -121,20 +122,29 @@ class DiffusionProcess:
                 sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
                 return self._loop(latents, t_host, sig_dev)
             cap = self.max_graph_batch or max(1, 4096 * 256 // (latents.shape[-1] * latents.shape[-2]))
-            dual = lambda m: bool(self.dual_stream_min) and m >= self.dual_stream_min and m % 2 == 0  # noqa: E731
-            n = latents.shape[0]
-            if n > (2 * cap if dual(n) else cap):
-                # bulk generation (BASELINE config E): pieces of the largest size one replay can take, one after the other
-                piece = 2 * cap if dual(2 * cap) else cap
-                return torch.cat([self._sample_piece(latents[i:i + piece], t_steps, t_host, dual)
-                                  for i in range(0, n, piece)])
-            return self._sample_piece(latents, t_steps, t_host, dual)
+            return self._sample_any(latents, t_steps, t_host, cap)
         finally:
             self.net.train(was_training)
 
-    def _sample_piece(self, latents, t_steps, t_host, dual):
+    def _dual(self, m):
+        return bool(self.dual_stream_min) and m >= self.dual_stream_min and m % 2 == 0
+
+    def _sample_any(self, latents, t_steps, t_host, cap):
+        """Series per captured loop never exceed `cap` (every activation of a piece has to stay under the conv kernels'
+        2 GiB buffer-addressing limit).  A request above what one replay takes -- 2*cap as two concurrent half-batch
+        graphs, else cap -- is bulk generation (BASELINE config E): it is cut into pieces sampled one after the other;
+        an odd piece above cap, which cannot run as two halves, is cut again at cap."""
         n = latents.shape[0]
-        if dual(n):
+        if n <= cap or (self._dual(n) and n <= 2 * cap):
+            return self._sample_piece(latents, t_steps, t_host)
+        piece = 2 * cap if self._dual(2 * cap) else cap
+        if n <= piece:
+            piece = cap
+        return torch.cat([self._sample_any(latents[i:i + piece], t_steps, t_host, cap) for i in range(0, n, piece)])
+
+    def _sample_piece(self, latents, t_steps, t_host):
+        n = latents.shape[0]
+        if self._dual(n):
             # Two half-batch graphs replayed side by side on two streams: the HBM-bound kernels of one half
             # (GroupNorm, 1x1 convs) run beside the matrix-core-bound 3x3 convs of the other (+2-3 % series/s).
             parts = latents.chunk(2)

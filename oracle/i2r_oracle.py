@@ -381,6 +381,17 @@ def perturb_zero_init(sd: Dict[str, torch.Tensor], seed: int = 1234, scale_mult:
                 w.copy_(torch.randn(w.shape, generator=gen) * (scale_mult * math.sqrt(1.0 / fan_in)))
 
 
+def perturb_norm_affine(sd: Dict[str, torch.Tensor], seed: int = 4321, spread: float = 0.3) -> None:
+    """In place: GroupNorm gamma <- 1 + spread*N(0,1), beta <- spread*N(0,1) (they are initialised to exactly 1 / 0,
+    networks.py:100-101, which would hide a wrong per-channel gamma/beta index).  Deterministic in key order."""
+    gen = torch.Generator().manual_seed(seed)
+    for key in sorted(sd.keys()):
+        if ".norm" in key or key.startswith(("model.out_norm", "out_norm")):
+            w = sd[key]
+            with torch.no_grad():
+                w.copy_(torch.randn(w.shape, generator=gen) * spread + (1.0 if key.endswith("weight") else 0.0))
+
+
 def ema_decay(num_updates: int, decay: float = 0.9999) -> float:
     """ema.py:29-31 after the increment."""
     return min(decay, (1 + num_updates) / (10 + num_updates))

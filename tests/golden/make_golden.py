@@ -34,7 +34,8 @@ from models.our import TS2img_Karras  # noqa: E402  (reference)
 from models.sampler import DiffusionProcess  # noqa: E402  (reference)
 from models.ema import LitEma  # noqa: E402  (reference)
 
-from oracle.i2r_oracle import perturb_zero_init  # noqa: E402  (ours; deterministic perturbation of zero-init layers)
+from oracle.i2r_oracle import perturb_norm_affine, perturb_zero_init  # noqa: E402  (ours; deterministic perturbations)
+from tests.helpers import FULLSIZE, fullsize_inputs, tensor_sha  # noqa: E402  (ours; seeded inputs shared with the tests)
 
 TINY = dict(img_resolution=8, input_channels=3, ch_mult=[1, 2], unet_channels=64, attn_resolution=[8, 4],
             delay=3, embedding=8, seq_len=24, batch_size=4, ema=True, ema_warmup=2, diffusion_steps=18,
@@ -295,13 +296,86 @@ def g6_ema():
     print("g6_ema done")
 
 
+# ---------------------------------------------------------------- G7 every BASELINE shape at full size
+def g7_fullsize(only=None):
+    """Shapes A, B1, C, D through the REFERENCE at full model size: init hashes of all 550 tensors,
+    D(x, sigma) for per-sample and 0-dim fp64 sigma, loss_fn_irregular + every parameter's gradient summary with the
+    random draws injected, one sampling(1, xT) fp64 output and its img_to_ts bits.  GroupNorm gamma/beta and the
+    zero-initialised layers are perturbed deterministically (oracle.perturb_*) so no index error can hide."""
+    import time
+    path = os.path.join(HERE, "g7_fullsize.npz")
+    out = dict(np.load(path)) if (only and os.path.exists(path)) else {}
+    ipath = os.path.join(HERE, "g7_init.json")
+    init = json.load(open(ipath)) if (only and os.path.exists(ipath)) else {}
+    for name in FULLSIZE:
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        args, S, d = fullsize_inputs(name)
+        C = args.input_channels
+        torch.manual_seed(0)
+        m = TS2img_Karras(args, "cpu")
+        sd = m.net.state_dict()
+        init[name] = {"nparams": int(sum(p.numel() for p in m.net.parameters())), "state_len": len(m.state_dict()),
+                      "sha": {k: hashlib.sha256(v.numpy().tobytes()).hexdigest()[:16] for k, v in sd.items()},
+                      "inputs": {k: tensor_sha(v) for k, v in d.items()}}
+        perturb_zero_init(sd, seed=1234)
+        perturb_norm_affine(sd, seed=4321)
+        m.eval()
+        with torch.no_grad():
+            out[name + "/D_per_sample"] = m.net(d["x"], d["sigma"]).numpy()
+            out[name + "/D_scalar_sigma"] = m.net(d["x"][:1].double(), torch.tensor(1.7, dtype=torch.float64)).numpy()
+        x_img = m.ts_to_img(d["ts"])
+        mask = torch.isnan(x_img).float() * -1 + 1
+        x_tilde = m.ts_to_img(d["ts_tilde"])
+        out[name + "/img_bits"] = bits(x_img.numpy())
+        real_randn, real_randn_like = torch.randn, torch.randn_like
+        try:
+            torch.randn = lambda *a, **k: d["rnd"].clone()
+            torch.randn_like = lambda t, **k: d["noise"].clone()
+            loss, to_log = m.loss_fn_irregular(x_tilde, mask)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        loss.backward()
+        out[name + "/loss_value"] = np.array([loss.item(), to_log["karras loss"]], dtype=np.float64)
+        names, summ, small, index = [], [], [], []
+        off = 0
+        for i, (k, p) in enumerate(m.net.named_parameters()):
+            names.append(k)
+            summ.append(grad_summary(p.grad, 9000 + i))
+            if p.numel() <= 1024:  # biases, norm weights: kept element by element
+                small.append(p.grad.numpy().ravel())
+                index.append([i, off, p.numel()])
+                off += p.numel()
+        out[name + "/grad_summary"] = np.stack(summ)
+        out[name + "/grad_small"] = np.concatenate(small)
+        out[name + "/grad_small_index"] = np.array(index, dtype=np.int64)
+        init[name]["grad_names"] = names
+        m.zero_grad()
+        proc = DiffusionProcess(args, m.net, (C, S, S))
+        with torch.no_grad():
+            res = proc.sampling(sampling_number=1, xT=d["xT"])
+        assert res.dtype == torch.float64 and tuple(res.shape) == (1, C, S, S)
+        out[name + "/sample"] = res.numpy()
+        out[name + "/sample_ts_bits"] = bits(m.img_to_ts(res).numpy())
+        print(f"g7 {name}: params {init[name]['nparams']} loss {loss.item():.6f} |sample|max {res.abs().max().item():.4f} "
+              f"({time.time() - t0:.1f} s)", flush=True)
+    np.savez_compressed(path, **out)
+    with open(ipath, "w") as f:
+        json.dump(init, f, indent=0)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7_fullsize(sys.argv[2:] or None)
+        sys.exit(0)
     g1_delay()
     g2_init()
     g3_layers()
     g4_net()
     g6_ema()
+    g7_fullsize()
     for f in sorted(os.listdir(HERE)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(HERE, f)))

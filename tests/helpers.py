@@ -45,3 +45,52 @@ def rel_err(a, b):
 def probe_vec(n, seed):
     """Deterministic probe for the gradient summaries in g4_net.npz (same as tests/golden/make_golden.py)."""
     return np.random.default_rng(seed).standard_normal(n)
+
+
+def rms_rel_err(a, b):
+    """sqrt(mean |a-b|^2) / sqrt(mean |b|^2): the RMS-relative companion of rel_err (a large element cannot hide the
+    error of the small ones as it can in max/max)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+def chan_rel_err(a, b):
+    """Worst per-channel max|a-b| / max|b| over axis 1 of (B, C, ...) arrays: every channel is held to the bar on its
+    own scale."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    ax = tuple(i for i in range(a.ndim) if i != 1)
+    num = np.abs(a - b).max(axis=ax)
+    den = np.maximum(np.abs(b).max(axis=ax), 1e-30)
+    return float((num / den).max())
+
+
+# ---------------------------------------------------------------- full-size golden cases (tests/golden/g7_fullsize.npz)
+FULLSIZE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768")
+
+
+def fullsize_inputs(name):
+    """Seeded inputs of the full-size golden case `name` -- regenerated identically by tests/golden/make_golden.py
+    (which feeds them to the imported reference) and by the tests (torch's CPU generator is deterministic; the fixture
+    stores a checksum of every tensor made here)."""
+    import torch
+    from imageni2r_amd.workloads import image_side, workload_args
+    args = workload_args(name, device="cpu")
+    S, C, L = image_side(args), args.input_channels, args.seq_len
+    g = torch.Generator().manual_seed(7000 + FULLSIZE.index(name))
+    d = {"x": torch.randn(2, C, S, S, generator=g), "sigma": torch.tensor([0.3, 7.0])}
+    ts = torch.rand(2, L, C, generator=g)
+    for b in range(2):
+        ts[b, torch.randperm(L, generator=g)[: int(0.3 * L)], :] = float("nan")
+    d["ts"] = ts
+    d["ts_tilde"] = torch.rand(2, L, C, generator=g)
+    d["rnd"] = torch.randn(2, 1, 1, 1, generator=g)
+    d["noise"] = torch.randn(2, C, S, S, generator=g)
+    d["xT"] = torch.randn(1, C, S, S, generator=g)
+    return args, S, d
+
+
+def tensor_sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()[:16]

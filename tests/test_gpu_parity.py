@@ -557,19 +557,19 @@ def test_training_step_with_dropout_runs(tiny_gpu):
 def test_chunked_attention_tail_matches_whole_batch(tiny_gpu):
     """Inference at large batch runs norm2 -> qkv -> attention -> proj over sample chunks (cache residency); every
     series must come out exactly as from the whole-batch pass."""
-    from imageni2r_amd import networks
+    from imageni2r_amd import networks, ops
     net = tiny_gpu.net
     x = torch.randn(8, 3, 8, 8, generator=torch.Generator().manual_seed(9)).to(DEV)
     sig = torch.tensor([0.7], device=DEV)
     with torch.no_grad():
-        old = networks.UNetBlock.ATTN_CHUNK_BYTES
+        old = ops.knob("attn_chunk_bytes")
         try:
-            networks.UNetBlock.ATTN_CHUNK_BYTES = 0
+            ops.set_knob("attn_chunk_bytes", 0)
             ref = net(x, sig)
-            networks.UNetBlock.ATTN_CHUNK_BYTES = 3 * 64 * 64 * 4 * 2  # two samples' qkv at the 8x8 level
+            ops.set_knob("attn_chunk_bytes", 3 * 64 * 64 * 4 * 2)  # two samples' qkv at the 8x8 level
             blk = next(b for b in net.model.enc.values() if isinstance(b, networks.UNetBlock) and b.num_heads)
             assert blk._attn_chunk(torch.empty(8, 64, 8, 8)) == 2
             out = net(x, sig)
         finally:
-            networks.UNetBlock.ATTN_CHUNK_BYTES = old
+            ops.set_knob("attn_chunk_bytes", old)
     assert torch.equal(out, ref)
