@@ -27,6 +27,34 @@ def _state(obj):
     return obj.state_dict() if obj is not None else None
 
 
+def _plain(score):
+    """Scores arrive as numpy scalars (metrics/__init__.py:50 returns np.round(np.mean(..), 4)); a plain Python
+    number pickles without numpy globals, so the file stays loadable with ``weights_only=True``.  str() of a
+    numpy float64 and of the equal Python float are the same text, so the file name does not change."""
+    if score is None or type(score) in (bool, int, float, str):  # (numpy.float64 IS a float subclass: exact types)
+        return score
+    try:
+        return score.item() if hasattr(score, "item") else float(score)
+    except Exception:  # noqa: BLE001 -- an unexpected type is stored as the caller gave it
+        return score
+
+
+def _numpy_scalar_globals():
+    """The globals a pickled numpy scalar needs -- what reference-written checkpoints hold for the four scores.
+    Allow-listing them lets ``weights_only=True`` read such files without executing anything from them."""
+    import numpy as np
+    allowed = [np.dtype, np.float64, np.float32, np.int64]
+    try:
+        allowed.append(np._core.multiarray.scalar)
+    except AttributeError:  # numpy < 2
+        allowed.append(np.core.multiarray.scalar)
+    for name in ("Float64DType", "Float32DType", "Int64DType"):
+        t = getattr(np.dtypes, name, None)
+        if t is not None:
+            allowed.append(t)
+    return allowed
+
+
 def save_checkpoint(args, our_model, our_optimizer, ema_model, encoder, decoder, tst_optimizer, disc_score,
                     pred_score=None, fid_score=None, correlation_score=None):
     """Write the single best checkpoint of a run, replacing whatever the directory held (:55-62).  Like the reference
@@ -49,10 +77,10 @@ def save_checkpoint(args, our_model, our_optimizer, ema_model, encoder, decoder,
             "tst_encoder": _state(encoder),
             "tst_decoder": _state(decoder),
             "tst_optimizer": _state(tst_optimizer),
-            "disc_score": disc_score,
-            "pred_score": pred_score,
-            "fid_score": fid_score,
-            "correlation_score": correlation_score,
+            "disc_score": _plain(disc_score),
+            "pred_score": _plain(pred_score),
+            "fid_score": _plain(fid_score),
+            "correlation_score": _plain(correlation_score),
             "args": {k: v for k, v in vars(args).items()},
         }, filepath)
         print(f"Checkpoint saved at: {filepath}")
@@ -79,11 +107,12 @@ def restore_checkpoint(ckpt_dir, state, ema_model=None, map_location="cpu"):
     present is loaded from its key of the file, and ``state['epoch']`` (read by utils/utils.py:29) is set from the
     file when it has one, else kept / 0.  The scores and the saved ``args`` are put under the same names as in the
     file.  ``ema_model``: a LitEma to load separately (the copy inside ``our_model_state_dict`` under ``model_ema.*``
-    is loaded with the model anyway).  The file is read with ``weights_only=True``: tensors and plain Python values
-    only, nothing in it is executed.
+    is loaded with the model anyway).  The file is read with ``weights_only=True``: tensors, plain Python values and
+    numpy scalars (the reference stores its scores as numpy.float64) only; nothing in it is executed.
     """
     path = find_checkpoint(ckpt_dir)
-    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
     for key, name in (("our_model_state_dict", "model"), ("our_optimizer_state_dict", "optimizer"),
                       ("tst_encoder", "encoder"), ("tst_decoder", "decoder"), ("tst_optimizer", "tst_optimizer")):
         target = state.get(name)

@@ -83,7 +83,7 @@ class TS2img_Karras(nn.Module):
         if augment_pipe is not None or labels is not None:
             raise NotImplementedError("augment_pipe / labels are never passed by ImagenI2R")
         rnd, noise = self._injected if self._injected is not None else (None, None)
-        seed = torch.initial_seed() & ((1 << 63) - 1)
+        seed = ops.rng_seed()
         step = ops.rng_step()
         xn, sigma, weight = ops.edm_noise(x.detach().contiguous(), mask, self.P_mean, self.P_std, self.sigma_data,
                                           rnd=rnd, noise=noise, seed=seed,

@@ -155,7 +155,7 @@ class GroupNorm(torch.nn.Module):
             return y
         seed = offset = 0
         if drop_p > 0.0:
-            seed = torch.initial_seed() & ((1 << 63) - 1)
+            seed = ops.rng_seed()
             # host counter per call, or (device step counter, fixed layer id) when a graph owns the RNG step
             offset = self._rng_id if ops.rng_step() is not None else next(_dropout_counter)
         return ops.GroupNormFn.apply(x, self.weight, self.bias, scale_shift, self.num_groups, self.eps, act_silu,
@@ -402,9 +402,8 @@ class DhariwalUNet(torch.nn.Module):
         blocks = [b for b in list(self.enc.values()) + list(self.dec.values()) if isinstance(b, UNetBlock)]
         lins = [b.affine for b in blocks]
         need_grad = torch.is_grad_enabled() and (emb.requires_grad or lins[0].weight.requires_grad)
-        if need_grad and any(getattr(l.weight, "_grad_slot", None) is None or
-                             getattr(l.bias, "_grad_slot", None) is None for l in lins):
-            return None
+        if need_grad and any(ops.param_slot(l.weight) is None or ops.param_slot(l.bias) is None for l in lins):
+            return None  # no slots, or gradients are being accumulated over several backwards
         key = ops.AffinePlan.make_key(lins, emb.shape[0])
         plans = self.__dict__.setdefault("_affine_plans", {})  # per (batch rows, parameter / slot addresses)
         plan = plans.get(key)

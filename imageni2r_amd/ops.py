@@ -133,6 +133,25 @@ def set_rng_step(counter) -> None:
     _RNG_STEP[0] = counter
 
 
+_RNG_RANK = [None]  # override of the data-parallel rank folded into the training RNG seed (tests); None = ask torch.distributed
+
+
+def set_rng_rank(rank) -> None:
+    _RNG_RANK[0] = None if rank is None else int(rank)
+
+
+def rng_seed() -> int:
+    """Philox key of the training streams (sigma / noise draws, dropout masks): torch's seed with the data-parallel
+    rank folded in.  Data-parallel ranks must seed torch identically to build identical initial weights; without the
+    rank in the key every rank would then draw the same sigma, noise field and dropout masks for its local sample b,
+    and a global batch would hold each draw world-size times."""
+    rank = _RNG_RANK[0]
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return (torch.initial_seed() ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 63) - 1)
+
+
 def counter_add(counter, inc=1):
     _lib.call("i2r_counter_add_u64", _p(counter), int(inc), _stream())
 
@@ -148,6 +167,16 @@ def set_slots_zeroed(flag: bool) -> None:
     """Promise that every parameter's ``_grad_slot`` buffer was zero-filled at the start of this step: weight-gradient
     kernels then ADD into the slots (no per-layer memsets) instead of overwriting them."""
     _SLOTS_ZEROED[0] = bool(flag)
+
+
+def param_slot(param):
+    """The gradient slot the backward kernels may WRITE for this parameter, or None.  A parameter that already holds a
+    gradient (a second backward without zero_grad: gradient accumulation) gets None: its kernels then return a fresh
+    tensor and autograd adds it to ``.grad`` -- writing the slot again would hand autograd an alias of ``.grad`` itself
+    and double the last gradient instead of summing the two."""
+    if param is None or param.grad is not None:
+        return None
+    return getattr(param, "_grad_slot", None)
 
 
 def grad_slot(param):
@@ -619,7 +648,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.wpd = wpd  # weights already packed for the data gradient (DhariwalUNet.pack_all_weights), or None
-        ctx.slots = (getattr(w, "_grad_slot", None), getattr(bias, "_grad_slot", None))
+        ctx.slots = (param_slot(w), param_slot(bias))
         if wph is not None:  # forward on the f16x2-split kernel (~1e-6); the gradients below use the exact kernels
             return conv2d_fwd_h2(x, tuple(w.shape), wph, bias, None if residual is None else _c(residual))
         return conv2d_fwd(x, w, bias, None if residual is None else _c(residual), wp)
@@ -690,7 +719,7 @@ class GroupNormFn(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
             ctx.cfg = (groups, act, drop_p, seed, offset, step)
-            ctx.slots = (getattr(gamma, "_grad_slot", None), getattr(beta, "_grad_slot", None))
+            ctx.slots = (param_slot(gamma), param_slot(beta))
             ctx.dss_slot = dss_slot
         return (y, x.view_as(x)) if bypass else y
 
@@ -734,7 +763,7 @@ class LinearFn(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, w, pre)
             ctx.has_bias = bias is not None
-            ctx.slots = (getattr(w, "_grad_slot", None), getattr(bias, "_grad_slot", None))
+            ctx.slots = (param_slot(w), param_slot(bias))
         return y
 
     @staticmethod

@@ -32,6 +32,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._ema is not None:
             self._ema.fused_into_optimizer = True
         self._table_key = None
+        self.state_generation = 0  # bumped when load_state_dict swaps the state tensors (captured graphs go stale)
         self._flat_grad = None
         self.scalars = None  # device float[8]: [0] total grad norm of the last step, [1] its clip coefficient
 
@@ -124,7 +125,18 @@ class FusedAdamW(torch.optim.Optimizer):
         return p._grad_slot.data_ptr()
 
     def _key(self, ps):
-        return tuple((p.data_ptr(), self._gptr(p)) for p in ps)
+        """Everything the device pointer table holds: parameter, gradient, both moments (load_state_dict replaces those
+        tensors) and, through the generation, the EMA shadows."""
+        return (self.state_generation,) + tuple(
+            (p.data_ptr(), self._gptr(p), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+            for p in ps)
+
+    def load_state_dict(self, state_dict):
+        """torch's loader swaps in new ``exp_avg`` / ``exp_avg_sq`` / ``step`` tensors: the pointer table is rebuilt on
+        the next step and GraphedTrainStep re-captures (``state_generation``)."""
+        super().load_state_dict(state_dict)
+        self._table_key = None
+        self.state_generation += 1
 
     @torch.no_grad()
     def step(self, closure=None):

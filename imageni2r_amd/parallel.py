@@ -54,10 +54,18 @@ class GradBucketReducer:
     world size; call it after ``loss.backward()`` and before ``clip_grad_norm_`` / ``optimizer.step()`` (the clip
     norm is then identical on every rank without another collective).
     Works unchanged if the caller uses ``optimizer.zero_grad()`` (grads set to None): the hook re-binds the view.
+
+    Unequal per-rank batches (a loader without ``drop_last``, as the reference builds it, utils/utils_data.py:243, split
+    unevenly): the loss is a mean over the LOCAL elements, so the global gradient is the element-count-weighted mean
+    sum_r n_r g_r / sum_r n_r, not the plain mean.  Call ``set_local_count(n_local)`` before backward on every rank
+    (one 1-element all-reduce, no host sync; or pass ``n_total`` when the caller knows it -- no collective at all):
+    each bucket is then scaled by n_r / N before it is summed and ``finish()`` does not divide.  The weighting stays in
+    force until ``set_local_count(None)``.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
         self.group = group
+        self._weight = None      # device scalar n_local / N_total, or None = equal batches (plain mean)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.buckets: List[torch.Tensor] = []
@@ -101,6 +109,33 @@ class GradBucketReducer:
         b, off = self._slot[p]
         return self.buckets[b][off: off + p.numel()].view_as(p)
 
+    def set_local_count(self, n_local, n_total=None):
+        """Weight this rank's gradients by ``n_local / n_total`` (elements or samples -- any unit, as long as every
+        rank uses the same one).  ``n_total`` None: summed over the ranks here (a 1-element all-reduce on the
+        gradients' device, nothing is read back).  ``n_local`` None: back to the plain mean."""
+        if n_local is None:
+            self._weight = None
+            return
+        ref = self.buckets[0]
+        w = torch.tensor([float(n_local)], dtype=torch.float32, device=ref.device)
+        if n_total is None:
+            tot = w.clone()
+            if self.world > 1:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+            w = w / tot
+        else:
+            w = w / float(n_total)
+        self._weight = w
+
+    def _start(self, b):
+        flat = self.buckets[b]
+        if self._weight is not None:
+            flat.mul_(self._weight)
+        if self.world > 1:
+            self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[b] = True  # started (world 1: the weighting alone)
+
     def _on_grad(self, p):
         b, _ = self._slot[p]
         view = self._view(p)
@@ -108,26 +143,28 @@ class GradBucketReducer:
             view.copy_(p.grad)      # first step / after zero_grad(set_to_none=True): adopt the bucket storage
             p.grad = view
         self._arrived[b] += 1
-        if self._arrived[b] == self._need[b] and self.world > 1 and not self.defer:
-            self._work[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._arrived[b] == self._need[b] and not self.defer and (self.world > 1 or self._weight is not None):
+            self._start(b)
 
     def launch_all(self):
         """Start every bucket's all-reduce now (used when backward ran inside a replayed HIP graph, where the hooks
         do not fire)."""
-        if self.world > 1:
-            for b, flat in enumerate(self.buckets):
+        if self.world > 1 or self._weight is not None:
+            for b in range(len(self.buckets)):
                 if self._work[b] is None:
-                    self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._start(b)
 
     def finish(self):
         """Wait for every bucket and turn sums into means.  Buckets whose parameters got no gradient this step are
         reduced here (as zeros for the missing ones) so all ranks issue the same collectives."""
         for b, flat in enumerate(self.buckets):
-            if self.world > 1:
+            if self.world > 1 or self._weight is not None:
                 if self._work[b] is None:
-                    self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._work[b].wait()
-                flat.div_(self.world)
+                    self._start(b)
+                if self._work[b] is not True:
+                    self._work[b].wait()
+                if self._weight is None:
+                    flat.div_(self.world)  # equal batches: plain mean; weighted: the n_r / N factors already sum to 1
             self._work[b] = None
             self._arrived[b] = 0
 

@@ -32,7 +32,7 @@ class GraphedTrainStep:
         self.opt = optimizer
         self.reducer = reducer
         self.use_graph = use_graph
-        self._entry = None
+        self._entries = {}  # input shape -> captured step (the short last batch of an epoch gets its own, once)
         dev = next(model.net.parameters()).device
         if dev.type != "cuda":
             raise _lib.I2RError("GraphedTrainStep: the model must live on a HIP ('cuda') device; no CPU fallback")
@@ -65,15 +65,38 @@ class GraphedTrainStep:
             ops.set_rng_step(prev)
         return loss
 
+    def _training_state(self):
+        """Every tensor a train step writes: weights, Adam moments, the shared step counter, the optimiser's scalars,
+        EMA shadow weights + update counter, and the RNG step counter."""
+        ps = self.opt._params()
+        ts = list(ps)
+        for p in ps:
+            st = self.opt.state[p]
+            ts += [st["exp_avg"], st["exp_avg_sq"]]
+        ts += [self.opt.state[ps[0]]["step"], self.opt.scalars, self.rng_counter]
+        if getattr(self.model, "use_ema", False):
+            ts += [b for b in self.model.model_ema.buffers()]
+        return [t.detach() for t in ts]
+
     def _capture(self, x_tilde_img, mask):
         self.opt.prepare()
         static_x = x_tilde_img.clone()
         static_m = mask.clone()
         side = torch.cuda.Stream(device=static_x.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # real warm-up steps: allocator, lazy state, autograd graph shape
-            for _ in range(2):
-                self._eager(static_x, static_m)
+        with torch.cuda.stream(side), torch.no_grad():
+            # Warm-up (allocator, lazy state, autograd graph shape) runs two REAL steps -- and must leave no trace:
+            # the batch that triggers a capture gets exactly one update like every other batch (the reference's
+            # loop, run_irregular.py:220-230, has no such thing as a warm-up).  Snapshot, step twice, put back.
+            live = self._training_state()
+            saved = [t.clone() for t in live]
+            with torch.enable_grad():
+                for _ in range(2):
+                    self._eager(static_x, static_m)
+            torch._foreach_copy_(live, saved)
+            del saved
+            if getattr(self.model, "use_ema", False):
+                self.model.model_ema._n = None  # host mirror of num_updates: re-read from the restored buffer
         torch.cuda.current_stream().wait_stream(side)
         prev = ops.rng_step()
         ops.set_rng_step(self.rng_counter)
@@ -97,7 +120,9 @@ class GraphedTrainStep:
             if self.reducer is not None:
                 self.reducer.defer = False
                 self.reducer.finish()  # reset the arrival counters the capture-time hooks advanced
-        self._entry = (g1, g2, static_x, static_m, loss)
+        entry = (g1, g2, static_x, static_m, loss, self.opt.state_generation)
+        self._entries[tuple(static_x.shape)] = entry
+        return entry
 
     def __call__(self, x_tilde_img, mask):
         """One full train step; returns the loss as a 0-dim device tensor (valid until the next call)."""
@@ -107,9 +132,14 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: call model.train() first (dropout is part of the captured step)")
         if not self.use_graph:
             return self._eager(x_tilde_img, mask)
-        if self._entry is None or tuple(self._entry[2].shape) != tuple(x_tilde_img.shape):
-            self._capture(x_tilde_img, mask)
-        g1, g2, static_x, static_m, loss = self._entry
+        entry = self._entries.get(tuple(x_tilde_img.shape))
+        if entry is not None and entry[5] != self.opt.state_generation:
+            # load_state_dict() replaced the moment tensors the captured optimiser tail points at: capture again
+            self._entries.clear()
+            entry = None
+        if entry is None:
+            entry = self._capture(x_tilde_img, mask)
+        g1, g2, static_x, static_m, loss, _ = entry
         static_x.copy_(x_tilde_img)
         static_m.copy_(mask)
         g1.replay()

@@ -2,6 +2,9 @@
 (models/our.py:87-108).  No kernels run here."""
 import os
 
+import numpy as np
+import pytest
+
 import torch
 
 from tests.helpers import tiny_args
@@ -102,3 +105,32 @@ def test_save_checkpoint_reports_failure_instead_of_raising(tmp_path, capsys):
     assert ck.save_checkpoint(args, torch.nn.Linear(1, 1), torch.optim.SGD([torch.zeros(1, requires_grad=True)], 0.1),
                               None, None, None, None, 1.0) is None
     assert "Failed to save checkpoint" in capsys.readouterr().out
+
+
+def test_checkpoint_with_numpy_scores_as_the_metrics_stage_returns_them(tmp_path):
+    """metrics/__init__.py:50 hands back np.round(np.mean(..), 4) -- numpy.float64 scalars.  Ours are stored as plain
+    numbers (same file name); a file that holds numpy scalars, as the reference writes them, still restores."""
+    from imageni2r_amd import checkpoint as ck
+    args = tiny_args(model_save_path=str(tmp_path), seq_len=24, dataset="sine", missing_rate=0.3)
+    m = _model(4)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    disc = np.round(np.mean([0.12345, 0.2]), 4)
+    pred = np.round(np.mean([0.5, 0.25]), 4)
+    assert isinstance(disc, np.float64)
+    path = ck.save_checkpoint(args, m, opt, m.model_ema, None, None, None, disc, pred_score=pred)
+    assert os.path.basename(path) == f"disc_score_{disc}_pred_score_{pred}_fid_score_None_correlation_score_None.pth"
+    raw = torch.load(path, weights_only=True)  # nothing numpy in the pickle
+    assert type(raw["disc_score"]) is float and raw["disc_score"] == float(disc)
+    state = ck.restore_checkpoint(str(tmp_path), {"model": _model(5)})
+    assert state["disc_score"] == float(disc) and state["pred_score"] == float(pred)
+    # a reference-written file: the scores are pickled numpy scalars
+    ref_style = dict(raw)
+    ref_style["disc_score"], ref_style["pred_score"] = disc, pred
+    torch.save(ref_style, path)
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)
+    m6 = _model(6)
+    state = ck.restore_checkpoint(str(tmp_path), {"model": m6})
+    assert state["disc_score"] == disc and isinstance(state["disc_score"], np.float64)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m6.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -105,3 +105,128 @@ def test_reducer_single_process_is_identity():
     m(x).sum().backward()
     assert all(p.grad.data_ptr() == p._grad_slot.data_ptr() for p in m.parameters())
     assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The real gradient path of imageni2r_amd: backward "kernels" WRITE the gradient into the parameter's slot (a view of
+# the reducer's bucket) and return an alias of it, which autograd adopts as .grad without a copy.  No HIP on the CPU,
+# so a stand-in autograd.Function does exactly what ops.Conv2dFn / LinearFn / GroupNormFn do with ops.param_slot().
+class _SlotLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from imageni2r_amd import ops
+        ctx.save_for_backward(x, w)
+        ctx.slots = (ops.param_slot(w), ops.param_slot(b))
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        sw, sb = ctx.slots
+        dw, db = dy.t() @ x, dy.sum(0)
+        if sw is not None and sb is not None:
+            sw.detach().copy_(dw)  # "the kernel writes the slot"
+            sb.detach().copy_(db)
+            dw, db = sw.detach(), sb.detach()
+        return dy @ w, dw, db
+
+
+class _SlotNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.w1 = torch.nn.Parameter(torch.randn(16, 6) * 0.3)
+        self.b1 = torch.nn.Parameter(torch.randn(16) * 0.1)
+        self.w2 = torch.nn.Parameter(torch.randn(3, 16) * 0.3)
+        self.b2 = torch.nn.Parameter(torch.randn(3) * 0.1)
+
+    def forward(self, x):
+        return _SlotLinear.apply(torch.tanh(_SlotLinear.apply(x, self.w1, self.b1)), self.w2, self.b2)
+
+
+def _worker_unequal(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from imageni2r_amd import ops
+        torch.manual_seed(0)
+        x = torch.randn(8, 6)
+        y = torch.randn(8, 3)
+        spans = [(0, 5), (5, 8)]  # the short last batch of an epoch, split unevenly: 5 + 3 samples
+        b, e = spans[rank]
+        out = {}
+        for deferred in (False, True):
+            m = _SlotNet()
+            red = GradBucketReducer(m.parameters(), bucket_bytes=300)
+            assert len(red.buckets) >= 2
+            for step in range(2):
+                red.zero_grad()
+                red.set_local_count(e - b)           # elements are (e - b) * 3 on every rank: samples are the unit
+                red.defer = deferred
+                loss = ((m(x[b:e]) - y[b:e]) ** 2).mean()
+                loss.backward()
+                assert all(p.grad.data_ptr() == p._grad_slot.data_ptr() for p in m.parameters())  # written in place
+                if deferred:
+                    red.launch_all()                 # what GraphedTrainStep does after replaying its backward graph
+                red.finish()
+            out[deferred] = [p.grad.clone().numpy() for p in m.parameters()]
+            red.remove()
+        # plain mean (no weighting) with equal halves still works through the slot path
+        m = _SlotNet()
+        red = GradBucketReducer(m.parameters(), bucket_bytes=300)
+        hb, he = shard_range(8, rank, world)
+        ((m(x[hb:he]) - y[hb:he]) ** 2).mean().backward()
+        red.finish()
+        out["equal"] = [p.grad.clone().numpy() for p in m.parameters()]
+        # training RNG streams: same torch seed on every rank (identical initial weights), different Philox keys
+        out["seed"] = ops.rng_seed()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unequal_batches_slot_path_and_rank_rng_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unequal, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    x = torch.randn(8, 6)
+    y = torch.randn(8, 3)
+    m = _SlotNet()
+    ((m(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in m.parameters()]
+    for rank in range(world):
+        for key in (False, True, "equal"):
+            for g, r in zip(res[rank][key], ref):
+                assert torch.allclose(torch.from_numpy(g), r, rtol=1e-5, atol=1e-7), (rank, key)
+    assert res[0]["seed"] != res[1]["seed"]
+    assert res[0]["seed"] == torch.initial_seed() & ((1 << 63) - 1)  # rank 0 keeps the single-process streams
+
+
+def test_gradient_accumulation_over_two_backwards_sums_in_the_slot():
+    """A second backward without zero_grad: the parameter already holds a gradient, so the kernels must not write the
+    slot again (autograd would add the alias to itself and double the LAST gradient)."""
+    m = _SlotNet()
+    red = GradBucketReducer(m.parameters())
+    x1, x2 = torch.randn(4, 6), torch.randn(4, 6)
+    m(x1).sum().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m(x2).sum().backward()
+    red.zero_grad()
+    m(x2).sum().backward()
+    g2 = [p.grad.clone() for p in m.parameters()]
+    red.zero_grad()
+    m(x1).sum().backward()
+    m(x2).sum().backward()
+    for p, a, b in zip(m.parameters(), g1, g2):
+        assert torch.allclose(p.grad, a + b, rtol=1e-6, atol=1e-6)
+        assert p.grad.data_ptr() == p._grad_slot.data_ptr()

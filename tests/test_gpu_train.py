@@ -306,15 +306,14 @@ def test_graphed_train_step_matches_eager():
             ts[0, [2, 3], :] = float("nan")
             _, mask = m.ts_to_img_with_mask(ts.to(DEV))
             x_tilde = m.ts_to_img(torch.rand(4, 24, 3, generator=gen).to(DEV))
-            if it == 0 and not use_graph:  # the graph path spends two real warm-up steps on its first batch
-                step(x_tilde, mask)
-                step(x_tilde, mask)
             losses.append(step(x_tilde, mask).item())
         assert all(np.isfinite(losses))
         runs.append((losses, [p.detach().cpu().clone() for p in m.net.parameters()], int(step.rng_counter.item()),
                      int(m.model_ema.num_updates.item())))
     (le, pe, ce, ne), (lg, pg, cg, ng) = runs
-    assert ce == cg == 8 and ne == ng == 8  # stream capture records, it does not execute: counters match eager
+    # the capture's warm-up steps are undone and stream capture records without executing: every batch got exactly
+    # one update in both modes (run_irregular.py:220-230 has one optimiser step per batch)
+    assert ce == cg == 6 and ne == ng == 6
     for a, b in zip(le, lg):
         assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
     for a, b in zip(pe, pg):  # Adam's sign-like first steps amplify the last-bit noise of the atomics in wgrad
@@ -361,7 +360,7 @@ def test_ema_scope_between_graphed_steps(monkeypatch):
     before = [p.detach().clone() for p in m.net.parameters()]
     losses = [step(*batch()).item() for _ in range(3)]
     assert all(np.isfinite(losses)) and opt._table_key == key
-    assert int(m.model_ema.num_updates.item()) == 8  # 2 warm-up + 6 replays
+    assert int(m.model_ema.num_updates.item()) == 6  # one per batch: the capture's warm-up steps leave no trace
     assert any(not torch.equal(a, b) for a, b in zip(before, m.net.parameters()))  # the graph still trains THESE weights
     m.eval()
     with m.ema_scope():
