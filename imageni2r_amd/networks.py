@@ -408,8 +408,10 @@ class DhariwalUNet(torch.nn.Module):
         plans = self.__dict__.setdefault("_affine_plans", {})  # per (batch rows, parameter / slot addresses)
         plan = plans.get(key)
         if plan is None:
-            if len(plans) >= 8:
-                plans.clear()
+            # plans are a few KB of launch tables; captured graphs hold raw pointers into them, so none is ever
+            # dropped while the network lives (keys: batch rows x parameter/slot addresses -- a handful)
+            if len(plans) >= 256:
+                raise ops._lib.I2RError("affine_all: too many distinct (batch, parameter address) plans")
             plan = plans[key] = ops.AffinePlan(lins, emb.shape[0])
         flat = [t for l in lins for t in (l.weight, l.bias)]
         outs = ops.AffineAllFn.apply(emb, plan, *flat)

@@ -32,7 +32,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._ema is not None:
             self._ema.fused_into_optimizer = True
         self._table_key = None
-        self.state_generation = 0  # bumped when load_state_dict swaps the state tensors (captured graphs go stale)
+        self.state_generation = 0  # bumped when load_state_dict swaps the state tensors
+        self.table_generation = 0  # bumped whenever the device pointer tables are rebuilt (captured graphs go stale)
         self._flat_grad = None
         self.scalars = None  # device float[8]: [0] total grad norm of the last step, [1] its clip coefficient
 
@@ -116,6 +117,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
         self._partials = torch.empty(len(chunks), dtype=torch.float32, device=dev)
         self._nchunks = len(chunks)
+        self.table_generation += 1  # graphs captured against the previous tables are stale from here on
         self._ema_decay = float(self._ema.decay) if self._ema is not None else 0.0  # one host read, at table build
 
     @staticmethod
@@ -171,11 +173,16 @@ class FusedAdamW(torch.optim.Optimizer):
         return None
 
     def prepare(self):
-        """Build state + pointer table without stepping (call before capturing ``step()`` into a graph)."""
+        """Build state + pointer table without stepping (call before capturing ``step()`` into a graph).  The device
+        tables are rebuilt ONLY when an address they hold changed: a captured graph keeps raw pointers to them, and
+        replacing the tensors would leave an earlier capture replaying against freed memory (``table_generation``
+        tells GraphedTrainStep when that happened and its graphs must be captured again)."""
         ps = self.bind_grads()
         self._ensure_state(ps)
-        self._build_table(ps)
-        self._table_key = self._key(ps)
+        key = self._key(ps)
+        if key != self._table_key:
+            self._build_table(ps)
+            self._table_key = key
         return self
 
     def grad_norm(self):

@@ -65,6 +65,9 @@ class GraphedTrainStep:
             ops.set_rng_step(prev)
         return loss
 
+    def _generation(self):
+        return (self.opt.state_generation, self.opt.table_generation)
+
     def _training_state(self):
         """Every tensor a train step writes: weights, Adam moments, the shared step counter, the optimiser's scalars,
         EMA shadow weights + update counter, and the RNG step counter."""
@@ -120,7 +123,7 @@ class GraphedTrainStep:
             if self.reducer is not None:
                 self.reducer.defer = False
                 self.reducer.finish()  # reset the arrival counters the capture-time hooks advanced
-        entry = (g1, g2, static_x, static_m, loss, self.opt.state_generation)
+        entry = (g1, g2, static_x, static_m, loss, self._generation())
         self._entries[tuple(static_x.shape)] = entry
         return entry
 
@@ -133,8 +136,9 @@ class GraphedTrainStep:
         if not self.use_graph:
             return self._eager(x_tilde_img, mask)
         entry = self._entries.get(tuple(x_tilde_img.shape))
-        if entry is not None and entry[5] != self.opt.state_generation:
-            # load_state_dict() replaced the moment tensors the captured optimiser tail points at: capture again
+        if entry is not None and entry[5] != self._generation():
+            # the optimiser's device pointer tables were rebuilt since (load_state_dict() swapped the moment tensors,
+            # something re-bound a gradient): every captured optimiser tail points at freed tables -- capture again
             self._entries.clear()
             entry = None
         if entry is None:

