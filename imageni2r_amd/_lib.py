@@ -34,6 +34,8 @@ SIGNATURES = {
     "i2r_conv2d_pack_weight_h2": [P, P, I, I, I, P],
     "i2r_conv2d_splitk_h2_floats": [I, I, I, I, I, I],
     "i2r_conv2d_fwd_h2": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, P],
+    "i2r_conv2d_fwd_h2_noalloc_max_floats": [],
+    "i2r_conv2d_fwd_h2_noalloc": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "i2r_conv1x1_cat_fwd_h2": [P, P, I, I, P, P, P, P, P, L, I, I, I, I, P],
     "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
@@ -70,7 +72,7 @@ SIGNATURES = {
 }
 
 RETURNS_LONG = {"i2r_conv2d_packed_floats", "i2r_conv2d_splitk_floats", "i2r_conv2d_packed_h2_bytes",
-                "i2r_conv2d_splitk_h2_floats"}
+                "i2r_conv2d_splitk_h2_floats", "i2r_conv2d_fwd_h2_noalloc_max_floats"}
 
 _lib = None
 

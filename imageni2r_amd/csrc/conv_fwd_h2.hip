@@ -588,6 +588,61 @@ extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bi
                    x_is_split, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing (no counterpart in the reference; include/i2r_hip.h).  Its split-K
+// slabs live in this file-scope device array instead of a caller workspace.  `noalloc_scratch` below is a HOST-side
+// stand-in for the symbol, not a device address: host code only ever uses the per-device pointer that
+// hipGetSymbolAddress returns (every GPU holds its own copy of the array at its own address).
+#define I2R_NOALLOC_SCRATCH_FLOATS (4L << 20) /* 16 MiB per GPU, held until the process ends */
+static __device__ __align__(256) float noalloc_scratch[I2R_NOALLOC_SCRATCH_FLOATS];
+
+#include <mutex>
+static float* noalloc_scratch_ptr() {
+  static std::mutex mu;
+  static float* ptrs[64] = {nullptr};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    i2r_set_error("conv2d_fwd_h2_noalloc: cannot identify the current device");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[dev]) {  // once per device, with that device current
+    float* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(noalloc_scratch));
+    if (e != hipSuccess || !ptr) {
+      i2r_set_error("conv2d_fwd_h2_noalloc: hipGetSymbolAddress(noalloc_scratch) failed on device %d: %s", dev,
+                    hipGetErrorString(e));
+      return nullptr;
+    }
+    ptrs[dev] = ptr;
+  }
+  return ptrs[dev];
+}
+
+extern "C" long i2r_conv2d_fwd_h2_noalloc_max_floats(void) { return I2R_NOALLOC_SCRATCH_FLOATS; }
+
+extern "C" int i2r_conv2d_fwd_h2_noalloc(const float* x, const void* wp, const float* bias, const float* residual,
+                                         float* out, int B, int Cin, int H, int W, int Cout, int ksize,
+                                         int x_is_split, i2r_stream_t stream) {
+  I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (ksize == 1 || ksize == 3),
+              "conv2d_fwd_h2_noalloc: bad dimensions");
+  // the same plan i2r_conv2d_fwd_h2 makes when it is handed the workspace i2r_conv2d_splitk_h2_floats asks for
+  const bool may_split = !((x_is_split >> 1) & 1) && !((x_is_split >> 3) & 1);
+  long want = may_split ? i2r_conv2d_splitk_h2_floats(B, Cin, H, W, Cout, ksize) : 0;
+  I2R_REQUIRE(want <= I2R_NOALLOC_SCRATCH_FLOATS,
+              "conv2d_fwd_h2_noalloc: this shape (B=%d Cin=%d %dx%d Cout=%d k=%d) wants %ld floats of split-K scratch, "
+              "above the built-in %ld; call i2r_conv2d_fwd_h2 with a caller-owned workspace instead",
+              B, Cin, H, W, Cout, ksize, want, (long)I2R_NOALLOC_SCRATCH_FLOATS);
+  float* scratch = nullptr;
+  if (want > 0) {
+    scratch = noalloc_scratch_ptr();
+    if (!scratch) return I2R_ERR_HIP;
+  }
+  // every slab element the reduction reads is written by exactly one workgroup of this call first: nothing to clear
+  return h2_launch(x, nullptr, Cin, wp, bias, residual, out, scratch, want, B, Cin, H, W, Cout, ksize, x_is_split,
+                   stream);
+}
+
 // 1x1 convolution over the channel concatenation [x1 | x2] (C1 + C2 input channels) without materialising it.
 extern "C" int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, int C2, const void* wp,
                                       const float* bias, const float* residual, float* out, float* splitk_ws,

@@ -80,6 +80,19 @@ long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksi
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       int x_is_split, i2r_stream_t stream);
+/* i2r_conv2d_fwd_h2 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that may
+ * not call hipMalloc or hand over a workspace -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  Same arithmetic, same kernels, same split-K plan and therefore the same bits as
+ * i2r_conv2d_fwd_h2 given the workspace i2r_conv2d_splitk_h2_floats asks for, but the split-K slabs live in a
+ * file-scope device array whose float count the _max_floats query below returns (16 MiB, one copy per GPU the library runs
+ * on, held until the process ends).  A shape whose plan wants more is rejected with an error (use the workspace
+ * variant); shapes that need no split-K use no scratch at all.  The function calls no hipMalloc / hipFree or any
+ * allocating routine.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; serialise them.  Nothing in the array has to be cleared between calls.  Make the FIRST call on each
+ * device outside stream capture (it looks the array's device address up once per device). */
+long i2r_conv2d_fwd_h2_noalloc_max_floats(void);
+int i2r_conv2d_fwd_h2_noalloc(const float* x, const void* wp, const float* bias, const float* residual, float* out,
+                              int B, int Cin, int H, int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream);
 /* 1x1 convolution over torch.cat([x1, x2], dim=1) (:458 feeding a block's `skip` conv, :156-159) without materialising
  * the concatenation; C1 a multiple of 16; weights packed for Cin = C1 + C2 by i2r_conv2d_pack_weight_h2. */
 int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, int C2, const void* wp, const float* bias,
