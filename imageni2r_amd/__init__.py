@@ -4,7 +4,9 @@ Drop-in classes (same names / signatures / state-dict keys as the reference's mo
     TS2img_Karras, EDMPrecond, DhariwalUNet, UNetBlock, Conv2d, GroupNorm, Linear, PositionalEmbedding,
     DelayEmbedder, DiffusionProcess, LitEma
 MI355X-side additions (no counterpart in the reference): FusedAdamW (clip + AdamW + EMA in one multi-tensor kernel
-step), GraphedTrainStep (the whole train step as one replayed HIP graph).
+step), GraphedTrainStep (the whole train step as one replayed HIP graph), set_deterministic (reproducible gradient
+summation order), tst_boundary.TrainIteration (the reference's loop body on the TST / diffusion step boundary) and
+metrics (the evaluation stage's scores, kept on the device).
 All arithmetic runs in libi2r_hip.so (imageni2r_amd/csrc, C ABI in include/i2r_hip.h); importing this package does not
 need a GPU, calling an op does (there is no CPU fallback).
 """
@@ -13,10 +15,10 @@ from .delay import DelayEmbedder
 from .ema import LitEma
 from .karras import TS2img_Karras
 from .sampler import DiffusionProcess
-from .ops import conv_math, set_conv_math
+from .ops import conv_math, set_conv_math, set_deterministic
 from .optim import FusedAdamW
 from .train import GraphedTrainStep
 
 __all__ = ["TS2img_Karras", "EDMPrecond", "DhariwalUNet", "UNetBlock", "Conv2d", "GroupNorm", "Linear",
            "PositionalEmbedding", "DelayEmbedder", "DiffusionProcess", "LitEma", "conv_math", "set_conv_math", "FusedAdamW",
-           "GraphedTrainStep"]
+           "GraphedTrainStep", "set_deterministic"]

@@ -38,6 +38,8 @@ SIGNATURES = {
     "i2r_conv2d_fwd_h2_noalloc": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "i2r_conv1x1_cat_fwd_h2": [P, P, I, I, P, P, P, P, P, L, I, I, I, I, P],
     "i2r_conv2d_wgrad_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "i2r_conv2d_wgrad_det_floats": [I, I, I, I, I, I],
+    "i2r_conv2d_wgrad_det_f32": [P, P, P, P, P, L, I, I, I, I, I, I, I, P],
     "i2r_down2_f32": [P, P, L, I, I, F, P],
     "i2r_up2_f32": [P, P, L, I, I, F, P],
     "i2r_concat_channels_f32": [P, P, P, I, L, L, P],
@@ -72,7 +74,8 @@ SIGNATURES = {
 }
 
 RETURNS_LONG = {"i2r_conv2d_packed_floats", "i2r_conv2d_splitk_floats", "i2r_conv2d_packed_h2_bytes",
-                "i2r_conv2d_splitk_h2_floats", "i2r_conv2d_fwd_h2_noalloc_max_floats"}
+                "i2r_conv2d_splitk_h2_floats", "i2r_conv2d_fwd_h2_noalloc_max_floats",
+                "i2r_conv2d_wgrad_det_floats"}
 
 _lib = None
 

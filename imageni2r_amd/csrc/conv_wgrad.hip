@@ -19,6 +19,8 @@ struct WgradParams {
   long Npos;
   int chunks_per_split, nsplit;
   int atomic;       // 1: add into dw/db with fp32 atomics (split reduction, or accumulate into existing values)
+  long slab_stride; // > 0 (deterministic mode): split z stores its partial dW, then its partial db, at dw + z * slab_stride
+                    // (a workspace; plain stores, no atomics) and wgrad_slab_reduce_kernel sums the slabs in z order
 };
 
 template <int WM, int WN, int TM, int TN, int KS>
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int e = 0; e < EA; ++e) bsum[e] = 0.0f;
   const bool want_bias = p.db != nullptr && blockIdx.x == 0;
+  float* const dw_out = p.dw + (long)blockIdx.z * p.slab_stride;
+  float* const db_out = p.slab_stride > 0 ? dw_out + (long)p.Cout * p.K : p.db;
   // Position of this thread's slot kk in the chunk being loaded, kept incrementally (one division per workgroup
   // instead of four per chunk: the loader, not the MFMA, was the busiest unit of this kernel).
   const long total_chunks = (p.Npos + BK - 1) / BK;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       for (int r = 0; r < 16; ++r) {
         int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (co < p.Cout) {
-          float* dst = p.dw + (long)co * p.K + j;
+          float* dst = dw_out + (long)co * p.K + j;
           if (p.atomic)
             atomicAdd(dst, acc[tm][tn][r]);
           else
@@ -156,28 +160,73 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       int co = m0 + i0 + 16 * e;
       if (kk == 0 && co < p.Cout) {
         if (p.atomic)
-          atomicAdd(p.db + co, v);
+          atomicAdd(db_out + co, v);
         else
-          p.db[co] = v;
+          db_out[co] = v;
       }
     }
   }
 }
 
+// Deterministic mode: out[i] (+)= slab[0][i] + slab[1][i] + ... in that fixed order; n = Cout*K (+ Cout for the bias
+// gradient, which sits behind dW in every slab and goes to its own output).
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride,
+                                                                int nsplit, float* __restrict__ dw,
+                                                                float* __restrict__ db, long n_dw, long n_all,
+                                                                int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
+    float v = slabs[i];
+    for (int z = 1; z < nsplit; ++z) v += slabs[z * slab_stride + i];
+    float* dst = i < n_dw ? dw + i : db + (i - n_dw);
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
-template <int WM, int WN, int TM, int TN>
-static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  long tiles = (long)i2r_cdiv(p.K, BN) * i2r_cdiv(p.Cout, BM);
-  long total_chunks = (p.Npos + BK - 1) / BK;
+static void wgrad_split_plan(long tiles, long Npos, int& chunks_per_split, int& nsplit) {
+  long total_chunks = (Npos + BK - 1) / BK;
   static const long target = getenv("I2R_WGRAD_TARGET") ? atol(getenv("I2R_WGRAD_TARGET")) : 1024;
   long want = (target + tiles - 1) / tiles;  // aim for ~4 blocks per CU
   if (want > total_chunks / 4) want = total_chunks / 4;  // keep >= 4 chunks per split
   static const long maxsplit = getenv("I2R_WGRAD_MAXSPLIT") ? atol(getenv("I2R_WGRAD_MAXSPLIT")) : 1 << 20;
   if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;
-  p.chunks_per_split = (int)((total_chunks + want - 1) / want);
-  p.nsplit = (int)((total_chunks + p.chunks_per_split - 1) / p.chunks_per_split);
+  chunks_per_split = (int)((total_chunks + want - 1) / want);
+  nsplit = (int)((total_chunks + chunks_per_split - 1) / chunks_per_split);
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_wgrad_det(WgradParams& p, int ks, float* ws, float* dw, float* db, int accumulate, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  wgrad_split_plan((long)i2r_cdiv(p.K, BN) * i2r_cdiv(p.Cout, BM), p.Npos, p.chunks_per_split, p.nsplit);
+  const long n_dw = (long)p.Cout * p.K, n_all = n_dw + (db ? p.Cout : 0);
+  p.dw = ws;                       // every split writes its own slab with plain stores
+  p.db = db ? ws : nullptr;        // (non-null = "bias wanted"; the kernel derives the slab's db address itself)
+  p.atomic = 0;
+  p.slab_stride = n_dw + p.Cout;
+  dim3 grid(i2r_cdiv(p.K, BN), i2r_cdiv(p.Cout, BM), p.nsplit);
+  if (ks == 3)
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 3>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, s, p);
+  int nb = i2r_cdiv(n_all, 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, s, ws, p.slab_stride, p.nsplit, dw, db, n_dw,
+                     n_all, accumulate);
+}
+
+template <int WM, int WN, int TM, int TN>
+static long wgrad_det_floats(int K, int Cout, long Npos) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  int cps, ns;
+  wgrad_split_plan((long)i2r_cdiv(K, BN) * i2r_cdiv(Cout, BM), Npos, cps, ns);
+  return (long)ns * ((long)Cout * K + Cout);
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_wgrad(WgradParams& p, int ks, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  wgrad_split_plan((long)i2r_cdiv(p.K, BN) * i2r_cdiv(p.Cout, BM), p.Npos, p.chunks_per_split, p.nsplit);
   if (p.nsplit > 1 && !p.atomic) {  // split reduction into fresh outputs: zero them, then add atomically
     (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
     if (p.db) (void)hipMemsetAsync(p.db, 0, sizeof(float) * (size_t)p.Cout, s);
@@ -203,7 +252,7 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size %d unsupported (1 or 3)", ksize);
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_wgrad: non-positive dimension");
   WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1,
-                accumulate ? 1 : 0};
+                accumulate ? 1 : 0, 0};
   hipStream_t s = (hipStream_t)stream;
   if (Cout <= 32)
     launch_wgrad<1, 4, 1, 1>(p, ksize, s);
@@ -214,4 +263,43 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   else
     launch_wgrad<2, 2, 1, 1>(p, ksize, s);
   return i2r_check_launch("conv2d_wgrad");
+}
+
+// Which tile shape a problem gets (shared by the two deterministic entry points so that the workspace query and the
+// launch agree).
+static int wgrad_variant(int K, int Cout, long Npos) {
+  if (Cout <= 32) return 0;
+  if (K <= 32) return 1;
+  if ((long)i2r_cdiv(K, 128) * i2r_cdiv(Cout, 128) >= 8 && Cout > 64 && Npos >= wgrad_big_pos()) return 2;
+  return 3;
+}
+
+extern "C" long i2r_conv2d_wgrad_det_floats(int B, int Cin, int H, int W, int Cout, int ksize) {
+  const int K = Cin * ksize * ksize;
+  const long Npos = (long)B * H * W;
+  switch (wgrad_variant(K, Cout, Npos)) {
+    case 0: return wgrad_det_floats<1, 4, 1, 1>(K, Cout, Npos);
+    case 1: return wgrad_det_floats<4, 1, 1, 1>(K, Cout, Npos);
+    case 2: return wgrad_det_floats<2, 2, 2, 2>(K, Cout, Npos);
+    default: return wgrad_det_floats<2, 2, 1, 1>(K, Cout, Npos);
+  }
+}
+
+extern "C" int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* dw, float* dbias, float* ws,
+                                        long ws_floats, int B, int Cin, int H, int W, int Cout, int ksize,
+                                        int accumulate, i2r_stream_t stream) {
+  I2R_REQUIRE(x && dy && dw && ws, "conv2d_wgrad_det: null pointer");
+  I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad_det: kernel size %d unsupported (1 or 3)", ksize);
+  I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_wgrad_det: non-positive dimension");
+  const long need = i2r_conv2d_wgrad_det_floats(B, Cin, H, W, Cout, ksize);
+  I2R_REQUIRE(ws_floats >= need, "conv2d_wgrad_det: workspace of %ld floats, needs %ld", ws_floats, need);
+  WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  switch (wgrad_variant(p.K, Cout, p.Npos)) {
+    case 0: launch_wgrad_det<1, 4, 1, 1>(p, ksize, ws, dw, dbias, accumulate, s); break;
+    case 1: launch_wgrad_det<4, 1, 1, 1>(p, ksize, ws, dw, dbias, accumulate, s); break;
+    case 2: launch_wgrad_det<2, 2, 2, 2>(p, ksize, ws, dw, dbias, accumulate, s); break;
+    default: launch_wgrad_det<2, 2, 1, 1>(p, ksize, ws, dw, dbias, accumulate, s); break;
+  }
+  return i2r_check_launch("conv2d_wgrad_det");
 }

@@ -20,7 +20,11 @@ struct OptEntry {  // one parameter tensor; mirrors the (T, 6) int64 table built
 };
 
 // scalars[]: 0 total_norm, 1 clip_coef, 2 step_size (lr / bias_correction1), 3 sqrt(bias_correction2),
-//            4 ema (1 - decay), 5 ema mode (0 off, 1 copy, 2 lerp)
+//            4 ema (1 - decay), 5 ema mode (0 off, 1 copy, 2 lerp), 6 steps skipped so far, 7 skip THIS step (0/1)
+// Guard (only when clipping is on, i.e. the norm is computed anyway): a step whose total gradient norm is not finite
+// is SKIPPED -- no weight, moment, EMA or counter changes -- and counted in scalars[6].  torch's clip_grad_norm_ +
+// AdamW would turn every weight into NaN there (the reference has no guard, run_irregular.py:228-229); with finite
+// gradients the two are identical.
 __global__ __launch_bounds__(256) void opt_sumsq_kernel(const OptEntry* __restrict__ tab,
                                                         const int2* __restrict__ chunks,
                                                         float* __restrict__ partials) {
@@ -71,6 +75,13 @@ __global__ __launch_bounds__(256) void opt_scalars_kernel(const float* __restric
       coef = max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
       if (coef > 1.0f) coef = 1.0f;
     }
+    const bool skip = max_norm > 0.0f && !(total <= 3.0e38f);  // inf or NaN gradient norm
+    scalars[0] = total;
+    scalars[7] = skip ? 1.0f : 0.0f;
+    if (skip) {
+      scalars[6] += 1.0f;
+      return;
+    }
     float t = step[0] + 1.0f;
     step[0] = t;
     double bc1 = 1.0 - pow((double)beta1, (double)t);
@@ -119,6 +130,7 @@ __global__ __launch_bounds__(256) void opt_adamw_ema_kernel(const OptEntry* __re
   const long start = (long)ch.y * OPT_CHUNK;
   long cnt = e.n - start;
   if (cnt > OPT_CHUNK) cnt = OPT_CHUNK;
+  if (scalars[7] != 0.0f) return;  // non-finite gradient norm: the whole step is skipped (uniform over the grid)
   const float coef = scalars[1], step_size = scalars[2], isb2 = scalars[3], omd = scalars[4];
   const int mode = e.ema ? (int)scalars[5] : 0;
   const float decay_mul = 1.0f - lr * weight_decay;

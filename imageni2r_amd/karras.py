@@ -7,6 +7,7 @@ Same constructor (``args`` namespace, ``device``), attributes and methods: ``net
 from __future__ import annotations
 
 import itertools
+import math
 import os
 from contextlib import contextmanager
 
@@ -74,7 +75,20 @@ class TS2img_Karras(nn.Module):
         output, weight = self.forward_irregular(x, mask)
         # unpad(.., x.shape) of :64-65 are no-ops; loss = mean(weight * (out*mask - x*mask)^2) (:66)
         loss = ops.MaskedLossFn.apply(output, x.detach(), mask, weight.reshape(-1).contiguous())
-        to_log['karras loss'] = loss.detach().item()
+        value = loss.detach().item()
+        if not math.isfinite(value) and torch.is_grad_enabled() and ops.train_fwd_h2_enabled():
+            # fp16 range guard: a training forward on the f16x2 kernels met |activation| >= 65504 (inf there, finite
+            # in the reference's fp32 convs).  From here on every training forward uses the exact fp32 kernels.
+            import warnings
+            warnings.warn("loss_fn_irregular: non-finite loss with f16x2 training forwards (|activation| >= 65504?); "
+                          "switching the training forward to the exact fp32 kernels and recomputing this step",
+                          RuntimeWarning, stacklevel=2)
+            ops.set_train_fwd_h2("0")
+            ops.new_pack_epoch()
+            output, weight = self.forward_irregular(x, mask)
+            loss = ops.MaskedLossFn.apply(output, x.detach(), mask, weight.reshape(-1).contiguous())
+            value = loss.detach().item()
+        to_log['karras loss'] = value
         return loss, to_log
 
     def forward_irregular(self, x, mask, labels=None, augment_pipe=None):

@@ -109,12 +109,33 @@ def train_fwd_h2(npos=None) -> bool:
     return npos is not None and npos >= _TRAIN_FWD_H2_MINPOS[0]
 
 
+def train_fwd_h2_enabled() -> bool:
+    """May ANY training conv forward run on the f16x2 kernel (whose operands must stay below fp16's 65504)?"""
+    return h2_math() and _TRAIN_FWD_H2[0] != "0"
+
+
 def set_train_fwd_h2(mode) -> None:
     """"auto" (default), True / "1" (every conv) or False / "0" (exact fp32 forward everywhere)."""
     mode = {True: "1", False: "0"}.get(mode, mode)
     if mode not in ("auto", "0", "1"):
         raise ValueError(mode)
     _TRAIN_FWD_H2[0] = mode
+
+
+_DETERMINISTIC = [bool(os.environ.get("I2R_DETERMINISTIC"))]
+
+
+def deterministic() -> bool:
+    return _DETERMINISTIC[0]
+
+
+def set_deterministic(flag: bool) -> None:
+    """Run-to-run reproducible gradients: the conv weight gradients reduce their position splits through per-split
+    slabs added in a fixed order (i2r_conv2d_wgrad_det_f32) instead of fp32 atomics, and GroupNorm's dgamma / dbeta go
+    through per-sample partials and an ordered row reduction instead of atomic accumulation.  Everything else on the
+    path already has a fixed summation order.  A few per cent slower; a graph-replayed step is then bit-identical to
+    the same step run eagerly.  (Env: I2R_DETERMINISTIC=1.)  Captured graphs keep the mode they were captured in."""
+    _DETERMINISTIC[0] = bool(flag)
 
 
 _RNG_STEP = [None]  # device uint64 step counter of the training RNG streams (set by GraphedTrainStep), or None
@@ -370,6 +391,12 @@ def conv2d_wgrad(x, dy, ksize, want_bias=True, dw=None, db=None, accumulate=Fals
             db = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
         else:
             db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    if deterministic():
+        n = _lib.query("i2r_conv2d_wgrad_det_floats", B, Cin, H, W, Cout, ksize)
+        ws = torch.empty((n,), dtype=torch.float32, device=x.device)
+        _lib.call("i2r_conv2d_wgrad_det_f32", _p(x), _p(dy), _p(dw), _p(db) if want_bias else None, _p(ws), n, B, Cin,
+                  H, W, Cout, ksize, int(bool(accumulate)), _stream())
+        return dw, (db if want_bias else None)
     _lib.call("i2r_conv2d_wgrad_f32", _p(x), _p(dy), _p(dw), _p(db) if want_bias else None, B, Cin, H, W, Cout,
               ksize, int(bool(accumulate)), _stream())
     return dw, (db if want_bias else None)
@@ -444,7 +471,7 @@ def groupnorm_bwd(x, gamma, beta, ss, mean, rstd, dy, groups, act, drop_p=0.0, s
         dss = None
     elif dss is None or tuple(dss.shape) != (B, 2 * C) or not dss.is_contiguous():
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
-    if dgamma is not None and dbeta is not None and slots_zeroed():
+    if dgamma is not None and dbeta is not None and slots_zeroed() and not deterministic():
         # the step's gradient slots were zero-filled: accumulate over the batch in place (no partials, no reduction)
         _lib.call("i2r_groupnorm_bwd_acc_f32", _p(x), _p(gamma), _p(beta), _p(ss), 0 if ss is None else ss.shape[0],
                   _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dss), _p(add), B, C, HW, groups,

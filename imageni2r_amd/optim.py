@@ -35,7 +35,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self.state_generation = 0  # bumped when load_state_dict swaps the state tensors
         self.table_generation = 0  # bumped whenever the device pointer tables are rebuilt (captured graphs go stale)
         self._flat_grad = None
-        self.scalars = None  # device float[8]: [0] total grad norm of the last step, [1] its clip coefficient
+        self.scalars = None  # device float[8]: [0] total grad norm of the last step, [1] its clip coefficient,
+                             # [6] steps skipped for a non-finite norm, [7] 1 if the last step was skipped
 
     # ------------------------------------------------------------------------------------------------------
     def _params(self):
@@ -184,6 +185,11 @@ class FusedAdamW(torch.optim.Optimizer):
             self._build_table(ps)
             self._table_key = key
         return self
+
+    def skipped_steps(self) -> int:
+        """Steps the kernel skipped because the total gradient norm was inf / NaN (host sync; only counted when
+        ``max_grad_norm`` is set).  Nothing -- weights, moments, step count, EMA -- is touched by a skipped step."""
+        return 0 if self.scalars is None else int(self.scalars[6].item())
 
     def grad_norm(self):
         """Total gradient norm measured by the last step (device scalar, as clip_grad_norm_ would have returned)."""

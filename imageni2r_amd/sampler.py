@@ -50,6 +50,9 @@ class DiffusionProcess:
         self._graphs = self.net.__dict__.setdefault("_i2r_sampler_graphs", {})
         self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
         self._streams = None
+        # fp16 range guard of the f16x2 kernels (DESIGN.md "range contract"): series that come back non-finite are
+        # sampled again on the exact fp32 kernels.  One isfinite reduction + host sync per sample() call; 0 = off.
+        self.range_check = os.environ.get("I2R_RANGE_CHECK", "1") != "0"
         # series per captured loop: bigger requests are sampled in pieces (every activation of a piece has to stay
         # under the conv kernels' 2 GiB buffer-addressing limit).  None = 4096 at 16x16 images, scaled with the area.
         self.max_graph_batch = int(os.environ["I2R_MAX_GRAPH_BATCH"]) if "I2R_MAX_GRAPH_BATCH" in os.environ else None
@@ -122,9 +125,37 @@ class DiffusionProcess:
                 sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
                 return self._loop(latents, t_host, sig_dev)
             cap = self.max_graph_batch or max(1, 4096 * 256 // (latents.shape[-1] * latents.shape[-2]))
-            return self._sample_any(latents, t_steps, t_host, cap)
+            out = self._sample_any(latents, t_steps, t_host, cap)
+            if self.range_check and ops.h2_math():
+                out = self._resample_overflowed(latents, out, t_steps, t_host)
+            return out
         finally:
             self.net.train(was_training)
+
+    def _resample_overflowed(self, latents, out, t_steps, t_host):
+        """The f16x2 kernels hold activations as f16 hi + lo pairs: a magnitude >= 65504 anywhere in the network
+        becomes inf there and reaches the output as inf / NaN -- never as a finite wrong number.  The reference's fp32
+        convs (models/networks.py:87) have no such limit, so series that came back non-finite are sampled again on
+        the exact fp32 kernels; if they are non-finite there too, that is the reference's own result."""
+        ok = torch.isfinite(out).flatten(1).all(dim=1)
+        if bool(ok.all()):
+            return out
+        import warnings
+        bad = (~ok).nonzero().flatten()
+        warnings.warn(f"DiffusionProcess.sample: {bad.numel()} of {out.shape[0]} series left the fp16 range of the "
+                      "f16x2 kernels (|activation| >= 65504); they are sampled again on the exact fp32 kernels",
+                      RuntimeWarning, stacklevel=3)
+        prev = ops.conv_math()
+        ops.set_conv_math("f32")
+        ops.new_pack_epoch()
+        try:
+            sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
+            out = out.clone()
+            out[bad] = self._loop(latents[bad].contiguous(), t_host, sig_dev)
+        finally:
+            ops.set_conv_math(prev)
+            ops.new_pack_epoch()
+        return out
 
     def _dual(self, m):
         return bool(self.dual_stream_min) and m >= self.dual_stream_min and m % 2 == 0

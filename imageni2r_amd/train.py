@@ -32,6 +32,9 @@ class GraphedTrainStep:
         self.opt = optimizer
         self.reducer = reducer
         self.use_graph = use_graph
+        self.range_check_every = 64   # calls between looks at the optimiser's skipped-step count (one host sync each)
+        self._calls = 0
+        self._skipped_seen = 0
         self._entries = {}  # input shape -> captured step (the short last batch of an epoch gets its own, once)
         dev = next(model.net.parameters()).device
         if dev.type != "cuda":
@@ -127,8 +130,35 @@ class GraphedTrainStep:
         self._entries[tuple(static_x.shape)] = entry
         return entry
 
+    def check_range(self) -> int:
+        """fp16 range guard for the replayed step (no per-step host sync): the fused optimiser SKIPS a step whose
+        gradient norm is not finite and counts it.  If steps were skipped since the last look and training forwards
+        run on the f16x2 kernels (operands must stay below 65504 there; the reference's fp32 convs have no such
+        limit), the forward is switched to the exact fp32 kernels and the step is captured again.  Returns the number
+        of newly skipped steps.  Called automatically every ``range_check_every`` steps; call it when logging."""
+        n = self.opt.skipped_steps()
+        new = n - self._skipped_seen
+        self._skipped_seen = n
+        if new > 0:
+            import warnings
+            if ops.train_fwd_h2_enabled():
+                warnings.warn(f"GraphedTrainStep: {new} step(s) had a non-finite gradient norm and were skipped; the "
+                              "training forward leaves the f16x2 kernels (fp16 range) for the exact fp32 kernels",
+                              RuntimeWarning, stacklevel=2)
+                ops.set_train_fwd_h2("0")
+                ops.new_pack_epoch()
+                self._entries.clear()
+            else:
+                warnings.warn(f"GraphedTrainStep: {new} step(s) had a non-finite gradient norm and were skipped "
+                              "(the forward is already exact fp32: the loss itself is not finite)",
+                              RuntimeWarning, stacklevel=2)
+        return new
+
     def __call__(self, x_tilde_img, mask):
         """One full train step; returns the loss as a 0-dim device tensor (valid until the next call)."""
+        self._calls += 1
+        if self.range_check_every and self._calls % self.range_check_every == 0:
+            self.check_range()
         x_tilde_img = x_tilde_img.detach().to(torch.float32).contiguous()
         mask = mask.to(device=x_tilde_img.device, dtype=torch.float32).contiguous()
         if not self.model.training:

@@ -102,6 +102,12 @@ int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, int C2, con
  * `accumulate` is set (gradient buffers zeroed once per step by the caller). */
 int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int H, int W,
                          int Cout, int ksize, int accumulate, i2r_stream_t stream);
+/* the same gradients with a run-to-run reproducible summation order (deterministic mode): every split of the position
+ * range stores its partial dW / dbias into its own slab of `ws` with plain stores and one more launch adds the slabs in
+ * split order -- no atomics.  ws_floats >= i2r_conv2d_wgrad_det_floats(...) of the same shape. */
+long i2r_conv2d_wgrad_det_floats(int B, int Cin, int H, int W, int Cout, int ksize);
+int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats,
+                             int B, int Cin, int H, int W, int Cout, int ksize, int accumulate, i2r_stream_t stream);
 /* resample_filter [1,1] (:64-65, :82-85): y = scale * 2x2 box sum (down; scale 0.25 forward) and
  * y = scale * nearest x2 (up; scale 1 forward); each is the other's adjoint with the scales swapped. */
 int i2r_down2_f32(const float* x, float* y, long planes, int H, int W, float scale, i2r_stream_t stream);
@@ -214,7 +220,9 @@ int i2r_heun_correct_f64(const double* x_hat, const double* x_next, const float*
  * ema_shadow|0, numel}; chunks: device (nchunks,2) int32 {tensor, chunk index} with opt_chunk_elems (query below) elements per
  * chunk; partials: nchunks floats; scalars: 8 floats (out: [0] total grad norm, [1] clip coefficient);
  * step: device float (AdamW step count, incremented here); ema_num_updates: LitEma's int32 counter (incremented here)
- * or NULL for no EMA.  max_norm <= 0 disables clipping.  All per-step state is device-resident: graph-capturable. */
+ * or NULL for no EMA.  max_norm <= 0 disables clipping.  All per-step state is device-resident: graph-capturable.
+ * With clipping on, a step whose total gradient norm is inf / NaN is skipped as a whole (nothing is written but
+ * scalars[0], scalars[7] = 1 and the skipped-step count scalars[6]); the reference would write NaN into every weight. */
 int i2r_opt_chunk_elems(void);
 int i2r_fused_adamw_ema_step(const void* table, const void* chunks, int nchunks, float* partials, float* scalars,
                              float* step, int* ema_num_updates, float max_norm, float lr, float beta1, float beta2,

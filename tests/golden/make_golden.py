@@ -365,8 +365,46 @@ def g7_fullsize(only=None):
         json.dump(init, f, indent=0)
 
 
+# ---------------------------------------------------------------- G8 evaluation metrics
+def metric_inputs(seed=0, n=160, L=24, C=6):
+    """Two seeded sets of series in (0, 1): 'real' = noisy sines, 'generated' = the same family with a different noise
+    level and phase law (distinguishable, but not trivially)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(L)[None, :, None]
+    f = rng.uniform(0.05, 0.3, (n, 1, C)); ph = rng.uniform(0, 2 * np.pi, (n, 1, C))
+    real = 0.5 + 0.4 * np.sin(2 * np.pi * f * t + ph) + 0.02 * rng.standard_normal((n, L, C))
+    f = rng.uniform(0.05, 0.3, (n, 1, C)); ph = rng.uniform(0, np.pi, (n, 1, C))
+    gen = 0.5 + 0.4 * np.sin(2 * np.pi * f * t + ph) + 0.05 * rng.standard_normal((n, L, C))
+    return real.astype(np.float32), gen.astype(np.float32)
+
+
+def g8_metrics():
+    from metrics.correlation_score import calculate_pearson_correlation  # (reference)
+    from metrics.discriminative_torch import discriminative_score_metrics  # (reference)
+    from metrics.predictive_metrics import predictive_score_metrics  # (reference)
+    real, gen = metric_inputs()
+    args = SimpleNamespace(input_size=real.shape[2], device="cpu")
+    out = {"n": int(real.shape[0]), "L": int(real.shape[1]), "C": int(real.shape[2]),
+           "real_sha": hashlib.sha256(real.tobytes()).hexdigest()[:16],
+           "gen_sha": hashlib.sha256(gen.tobytes()).hexdigest()[:16], "cases": []}
+    for seed in (0, 5):
+        np.random.seed(seed); torch.manual_seed(seed)
+        disc = float(discriminative_score_metrics(real, gen, args))
+        np.random.seed(seed); torch.manual_seed(seed)
+        pred = float(predictive_score_metrics(real, gen))
+        np.random.seed(seed); torch.manual_seed(seed)
+        corr = calculate_pearson_correlation(real, gen)
+        out["cases"].append({"seed": seed, "disc": disc, "pred": pred, "corr_mean": float(corr[0])})
+        print("g8 seed", seed, out["cases"][-1], flush=True)
+    with open(os.path.join(HERE, "g8_metrics.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_metrics()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         g7_fullsize(sys.argv[2:] or None)
         sys.exit(0)
@@ -376,6 +414,7 @@ if __name__ == "__main__":
     g4_net()
     g6_ema()
     g7_fullsize()
+    g8_metrics()
     for f in sorted(os.listdir(HERE)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -255,3 +255,60 @@ def test_dropout_keep_rate_per_layer_and_independence():
     # per-channel keep rates: no channel is systematically favoured
     ch = masks[(1, 1, 0)].reshape(B, C, H * H).mean(axis=(0, 2))
     assert np.abs(ch - 0.9).max() < 5 * np.sqrt(0.09 / (B * H * H))
+
+
+# ---------------------------------------------------------------------------------------------- deterministic mode
+@pytest.fixture()
+def deterministic():
+    from imageni2r_amd import ops
+    ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 64, 64, 8, 3), (2, 384, 128, 16, 1), (32, 128, 128, 16, 3),
+                                             (3, 12, 128, 16, 3), (5, 256, 12, 4, 3), (8, 512, 1024, 2, 1)])
+def test_deterministic_wgrad_matches_the_atomic_one_and_repeats_bit_for_bit(deterministic, B, Cin, Cout, H, k):
+    from imageni2r_amd import ops
+    gen = torch.Generator().manual_seed(B * Cin + Cout)
+    x = torch.randn(B, Cin, H, H, generator=gen).to(DEV)
+    dy = torch.randn(B, Cout, H, H, generator=gen).to(DEV)
+    dw1, db1 = ops.conv2d_wgrad(x, dy, k)
+    dw2, db2 = ops.conv2d_wgrad(x, dy, k)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)                       # reproducible
+    ops.set_deterministic(False)
+    dwa, dba = ops.conv2d_wgrad(x, dy, k)
+    ops.set_deterministic(True)
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (Cout, Cin, k, k), dy.double().cpu(), padding=k // 2)
+    assert rel_err(dw1.cpu().numpy(), ref.numpy()) < 1e-5
+    assert rel_err(dw1.cpu().numpy(), dwa.cpu().numpy()) < 1e-5
+    assert rel_err(db1.cpu().numpy(), dy.double().sum(dim=(0, 2, 3)).cpu().numpy()) < 1e-5
+    # accumulate into pre-filled slots, without a bias
+    slot = torch.full((Cout, Cin, k, k), 0.5, device=DEV)
+    ops.conv2d_wgrad(x, dy, k, want_bias=False, dw=slot, accumulate=True)
+    assert rel_err((slot - 0.5).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_deterministic_mode_makes_the_replayed_step_bit_identical_to_the_eager_one(deterministic):
+    """No atomics anywhere in the step => the graph replay and the eager sequence of the same kernels are the same
+    arithmetic in the same order: losses, weights, EMA shadows and Adam moments must be EQUAL, not close."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep
+    runs = []
+    for use_graph in (False, True):
+        m = _model()
+        opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+        step = GraphedTrainStep(m, opt, use_graph=use_graph)
+        losses = [step(x, k).item() for x, k in _batches(m, 6)]
+        p0 = next(iter(m.net.parameters()))
+        runs.append((losses, [p.detach().clone() for p in m.net.parameters()],
+                     [b.detach().clone() for b in m.model_ema.buffers()], opt.state[p0]["exp_avg_sq"].clone()))
+    (le, pe, ee, ve), (lg, pg, eg, vg) = runs
+    assert le == lg, (le, lg)
+    assert all(torch.equal(a, b) for a, b in zip(pe, pg))
+    assert all(torch.equal(a, b) for a, b in zip(ee, eg))
+    assert torch.equal(ve, vg)
+    # and the mode is reproducible run to run (a fresh model, the same six batches)
+    m = _model()
+    opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    step = GraphedTrainStep(m, opt)
+    assert [step(x, k).item() for x, k in _batches(m, 6)] == lg

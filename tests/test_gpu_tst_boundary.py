@@ -1,0 +1,112 @@
+"""SURVEY §8(f) row 3 -- the step boundary between the completion (TST) stage and the diffusion step: a
+requires-grad image is accepted and cut (dead gradient), the diffusion parameter gradients do not change,
+and the boundary iteration trains both stages like the reference's loop body (run_irregular.py:209-244)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import i2r_oracle as O
+from tests.helpers import rel_err, tiny_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model():
+    from imageni2r_amd import TS2img_Karras
+    torch.manual_seed(0)
+    m = TS2img_Karras(tiny_args(device=DEV), DEV)
+    O.perturb_zero_init(m.net.state_dict(), seed=1234)
+    return m.to(DEV).train()
+
+
+def _batch(seed=3, B=4):
+    g = torch.Generator().manual_seed(seed)
+    ts = torch.rand(B, 24, 3, generator=g)
+    for b in range(B):
+        ts[b, torch.randperm(24, generator=g)[:7], :] = float("nan")
+    return ts.to(DEV)
+
+
+def test_requires_grad_image_is_cut_and_parameter_gradients_are_unchanged():
+    from imageni2r_amd.tst_boundary import CompletionStandIn
+    m = _model().eval()  # dropout off: the two passes below must agree exactly
+    torch.manual_seed(1)
+    comp = CompletionStandIn(3, 24, dropout=0.0).to(DEV)
+    x_ts = _batch()
+    pm = ~torch.isnan(x_ts).any(dim=-1)
+    _, mask = m.ts_to_img_with_mask(x_ts)
+    gen = torch.Generator().manual_seed(9)
+    rnd, noise = torch.randn(4, generator=gen).to(DEV), torch.randn(4, 3, 8, 8, generator=gen).to(DEV)
+    grads = []
+    for detach in (False, True):
+        x_recon = comp(x_ts, pm)
+        assert x_recon.requires_grad
+        img = m.ts_to_img(x_recon.detach() if detach else x_recon)   # run_irregular.py:219 keeps the graph
+        assert img.requires_grad == (not detach)
+        m.zero_grad(); comp.zero_grad()
+        m.inject_randomness(rnd, noise)
+        try:
+            loss, log = m.loss_fn_irregular(img, mask)
+            loss.backward()
+        finally:
+            m.inject_randomness(None, None)
+        assert np.isfinite(log["karras loss"])
+        # nothing reaches the completion stage from the diffusion loss -- the reference computes that gradient and
+        # throws it away (optimizer_er.zero_grad(), run_irregular.py:241)
+        assert all(p.grad is None for p in comp.parameters())
+        grads.append([p.grad.detach().clone() for p in m.net.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b) or rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5  # (wgrad atomics: not bit-equal)
+
+
+def test_graphed_step_accepts_a_requires_grad_image():
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep
+    from imageni2r_amd.tst_boundary import CompletionStandIn
+    m = _model()
+    torch.manual_seed(1)
+    comp = CompletionStandIn(3, 24).to(DEV).train()
+    x_ts = _batch()
+    pm = ~torch.isnan(x_ts).any(dim=-1)
+    _, mask = m.ts_to_img_with_mask(x_ts)
+    opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    step = GraphedTrainStep(m, opt)
+    img = m.ts_to_img(comp(x_ts, pm))
+    assert img.requires_grad
+    for _ in range(3):
+        assert np.isfinite(step(img, mask).item())
+    assert all(p.grad is None for p in comp.parameters())
+
+
+def test_boundary_iteration_trains_both_stages_like_the_reference_loop_body():
+    """dropout-free completion stage => reusing its first forward for the recovery loss is exact: the boundary
+    iteration (graph, detached image, one forward, no empty_cache) and the reference-shaped one (eager, two forwards,
+    empty_cache) leave the same completion weights and the same recovery losses; diffusion weights agree to the
+    tolerance of the graph-vs-eager test."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep
+    from imageni2r_amd.tst_boundary import CompletionStandIn, TrainIteration
+    x_ts = _batch(seed=5)
+    runs = []
+    for boundary in (False, True):
+        m = _model().eval()  # diffusion dropout off, injected draws are not available inside a graph: eval() for both
+        m.train()
+        torch.manual_seed(1)
+        comp = CompletionStandIn(3, 24, dropout=0.0).to(DEV).train()
+        opt_er = torch.optim.Adam(comp.parameters())
+        if boundary:
+            fopt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0,
+                              ema=(m.model_ema, m.net))
+            it = TrainIteration(m, comp, opt_er, diffusion_step=GraphedTrainStep(m, fopt))
+        else:
+            it = TrainIteration(m, comp, opt_er, diffusion_optimizer=torch.optim.AdamW(m.parameters(), lr=1e-4,
+                                                                                        weight_decay=1e-5),
+                                reuse_completion=False, empty_cache=True)
+        losses = [tuple(float(v) for v in it(x_ts)) for _ in range(4)]
+        runs.append((losses, [p.detach().cpu().clone() for p in comp.parameters()]))
+    (la, ca), (lb, cb) = runs
+    for (d0, e0), (d1, e1) in zip(la, lb):
+        assert np.isfinite(d0) and np.isfinite(d1)
+        assert abs(e0 - e1) <= 1e-5 * abs(e0), (la, lb)   # recovery losses: same completion trajectory
+    for a, b in zip(ca, cb):
+        assert rel_err(b.numpy(), a.numpy()) < 1e-4
+    assert la[0][1] > la[-1][1]                               # and the completion stage is actually learning

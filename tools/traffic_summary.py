@@ -1,30 +1,49 @@
 #!/usr/bin/env python3
-"""Sum FETCH_SIZE / WRITE_SIZE (KiB, rocprofv3 --pmc, one counter per pass) over the conv_fwd_h2 3x3 dispatches of
-tools/eval_once.py and print the per-launch HBM traffic that bench.py reports as roofline.traffic.
-usage: traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <batch>"""
+"""Per kernel family: HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch)
+over tools/eval_once.py -- what bench.py reports as roofline.traffic.
+
+usage: traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <workload> <batch>
+
+Corrections (MI355X_MICROARCH.md, HBM section): WRITE_SIZE is exact for 16-B-per-lane streaming stores and float
+atomics.  FETCH_SIZE reports HALF the bytes of wide coalesced streaming reads (16 B per lane): doubled for the
+kernels whose reads are of that kind (GroupNorm: calibrated -- 2 x FETCH_SIZE = WRITE_SIZE = the tensor's bytes);
+taken as reported for the conv / attention kernels, whose activation reads are dword-per-lane (calibrated on the
+single-Cout-tile 3x3 layers: FETCH_SIZE = 1.1 x the input bytes, i.e. not halved).  `fetch_scale` records the factor."""
 import csv
 import json
 import sys
 
+FAMILIES = {  # family -> (kernel-name substrings, FETCH_SIZE correction factor)
+    "conv_fwd_h2_k3": (("conv_fwd_h2_kernel<3",), 1.0),
+    "conv_fwd_h2_k1": (("conv_fwd_h2_kernel<1",), 1.0),
+    "attention_fwd_h2": (("attn_fwd_h2_kernel",), 1.0),
+    "groupnorm_fwd": (("gn_fwd_reg_kernel", "gn_cat_fwd", "gn_fwd_cat"), 2.0),
+}
 
-def total(path, counter):
-    n, s = 0, 0.0
+
+def totals(path, counter):
+    out = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "conv_fwd_h2_kernel<3" in r["Kernel_Name"]:
-            n += 1
-            s += float(r["Counter_Value"])
-    return n, s * 1024.0
+        if r["Counter_Name"] != counter:
+            continue
+        for fam, (subs, _) in FAMILIES.items():
+            if any(s in r["Kernel_Name"] for s in subs):
+                n, s = out.get(fam, (0, 0.0))
+                out[fam] = (n + 1, s + float(r["Counter_Value"]) * 1024.0)
+    return out
 
 
-nf, fetch = total(sys.argv[1], "FETCH_SIZE")
-nw, write = total(sys.argv[2], "WRITE_SIZE")
-assert nf == nw and nf > 0, (nf, nw)
-out = {"kernel": "conv_fwd_h2_k3", "batch": int(sys.argv[4]), "launches": nf,
-       "fetch_bytes_per_launch": fetch / nf, "write_bytes_per_launch": write / nw,
-       "traffic_bytes_per_launch": (fetch + write) / nf,
-       "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes over tools/eval_once.py; WRITE_SIZE is exact "
-               "for these stores; FETCH_SIZE is taken as reported (MI355X_MICROARCH.md halves only 16-B-per-lane "
-               "streaming reads; this kernel's activation reads are dword-per-lane, and on the single-Cout-tile "
-               "layers FETCH_SIZE comes out at 1.1x the input bytes, i.e. not halved)"}
+fetch, write = totals(sys.argv[1], "FETCH_SIZE"), totals(sys.argv[2], "WRITE_SIZE")
+kernels = {}
+for fam, (_, scale) in FAMILIES.items():
+    if fam not in fetch or fam not in write:
+        continue
+    (nf, f), (nw, w) = fetch[fam], write[fam]
+    assert nf == nw and nf > 0, (fam, nf, nw)
+    kernels[fam] = {"launches": nf, "fetch_bytes_per_launch": f * scale / nf, "write_bytes_per_launch": w / nw,
+                    "traffic_bytes_per_launch": (f * scale + w) / nf, "fetch_scale": scale}
+out = {"workload": sys.argv[4], "batch": int(sys.argv[5]), "kernels": kernels,
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs over one eager evaluation "
+               "(tools/eval_once.py) at this batch; corrections per MI355X_MICROARCH.md, see tools/traffic_summary.py"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
