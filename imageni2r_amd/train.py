@@ -57,6 +57,8 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _eager(self, x_tilde_img, mask):
+        if self.opt._table_key is None:
+            self.opt.prepare()  # gradient slots exist from the FIRST step on: eager and replayed steps run the same kernels
         prev = ops.rng_step()
         ops.set_rng_step(self.rng_counter)
         try:
