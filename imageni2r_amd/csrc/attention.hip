@@ -93,47 +93,55 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(const float* __restri
   if (lse && h == 0) lse[(long)bh * T + q0 + l31] = m_run + logf(l_run);
 }
 
-// T <= 32: everything in LDS, 64 threads per (sample, head)
+// T <= TM (TM = 4, 16 or 32): everything in LDS, 64 threads per (sample, head).  The head's q/k/v slab is one
+// contiguous run of 192*T floats and its output one of 64*T: both are walked linearly (consecutive lanes, consecutive
+// addresses), and LDS is sized by TM so that the 2x2 / 4x4 levels keep 10+ workgroups per CU in flight -- at batch
+// 4096 these launches stream 270 MB each and were latency-bound at 1.2 TB/s with the fixed 32-wide layout.
+template <int TM>
 __global__ __launch_bounds__(64) void attn_fwd_small_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             float* __restrict__ lse, int heads, int T) {
-  __shared__ float Q[HD * 32], K[HD * 32], V[HD * 32], S[32 * 33];
+  __shared__ float QKV[3][HD * TM], S[TM * (TM + 1)];
   const int tid = threadIdx.x;
   const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
   const int C = heads * HD;
-  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
-  for (int idx = tid; idx < HD * T; idx += 64) {
-    int d = idx / T, t = idx % T;
-    Q[d * 32 + t] = base[(long)(3 * d + 0) * T + t];
-    K[d * 32 + t] = base[(long)(3 * d + 1) * T + t];
-    V[d * 32 + t] = base[(long)(3 * d + 2) * T + t];
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;  // row 3 d + s (s: q, k, v), T floats each
+  for (int idx = tid; idx < 3 * HD * T; idx += 64) {
+    int row = idx / T, t = idx - row * T;
+    int d = row / 3, sel = row - 3 * d;
+    QKV[sel][d * TM + t] = base[idx];
   }
   __syncthreads();
+  const float* Q = QKV[0];
+  const float* K = QKV[1];
+  const float* V = QKV[2];
   for (int idx = tid; idx < T * T; idx += 64) {
-    int qi = idx / T, ki = idx % T;
+    int qi = idx / T, ki = idx - qi * T;
     float acc = 0.0f;
-    for (int d = 0; d < HD; ++d) acc += Q[d * 32 + qi] * (K[d * 32 + ki] * 0.125f);
-    S[qi * 33 + ki] = acc;
+    for (int d = 0; d < HD; ++d) acc += Q[d * TM + qi] * (K[d * TM + ki] * 0.125f);
+    S[qi * (TM + 1) + ki] = acc;
   }
   __syncthreads();
   if (tid < T) {
-    float m = S[tid * 33];
-    for (int k = 1; k < T; ++k) m = fmaxf(m, S[tid * 33 + k]);
+    float* row = S + tid * (TM + 1);
+    float m = row[0];
+    for (int k = 1; k < T; ++k) m = fmaxf(m, row[k]);
     float sum = 0.0f;
     for (int k = 0; k < T; ++k) {
-      float e = expf(S[tid * 33 + k] - m);
-      S[tid * 33 + k] = e;
+      float e = expf(row[k] - m);
+      row[k] = e;
       sum += e;
     }
     float inv = 1.0f / sum;
-    for (int k = 0; k < T; ++k) S[tid * 33 + k] *= inv;
+    for (int k = 0; k < T; ++k) row[k] *= inv;
     if (lse) lse[(long)bh * T + tid] = m + logf(sum);
   }
   __syncthreads();
-  float* ob = out + ((long)b * C + (long)hd * HD) * T;
-  for (int qi = 0; qi < T; ++qi) {
+  float* ob = out + ((long)b * C + (long)hd * HD) * T;  // (channel, query) row-major: idx = c * T + qi
+  for (int idx = tid; idx < HD * T; idx += 64) {
+    int c = idx / T, qi = idx - c * T;
     float acc = 0.0f;
-    for (int k = 0; k < T; ++k) acc += S[qi * 33 + k] * V[tid * 32 + k];
-    ob[(long)tid * T + qi] = acc;
+    for (int k = 0; k < T; ++k) acc += S[qi * (TM + 1) + k] * V[c * TM + k];
+    ob[idx] = acc;
   }
 }
 
@@ -371,7 +379,12 @@ extern "C" int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, i
   I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   if (T <= 32) {
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
+    if (T <= 4)
+      hipLaunchKernelGGL(attn_fwd_small_kernel<4>, dim3(B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
+    else if (T <= 16)
+      hipLaunchKernelGGL(attn_fwd_small_kernel<16>, dim3(B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
+    else
+      hipLaunchKernelGGL(attn_fwd_small_kernel<32>, dim3(B * heads), dim3(64), 0, s, qkv, out, lse, heads, T);
   } else {
     I2R_REQUIRE(T % 32 == 0, "attention_fwd: T=%d must be <= 32 or a multiple of 32", T);
     if (T % 128 == 0)

@@ -21,17 +21,22 @@ _dropout_counter = itertools.count(1)
 _layer_ids = itertools.count(1)
 
 
+# init mode -> (draw, gain): `draw` consumes torch's global CPU generator exactly like the reference's initialisers
+# (networks.py:19-24: uniform modes draw rand()*2-1, normal modes randn()), so a seeded construction yields the
+# reference's bits; `gain` is the mode's scale from the fan sizes.
+_INIT_MODES = {
+    'xavier_uniform': (lambda shape: torch.rand(*shape) * 2 - 1, lambda fi, fo: np.sqrt(6 / (fi + fo))),
+    'xavier_normal': (lambda shape: torch.randn(*shape), lambda fi, fo: np.sqrt(2 / (fi + fo))),
+    'kaiming_uniform': (lambda shape: torch.rand(*shape) * 2 - 1, lambda fi, fo: np.sqrt(3 / fi)),
+    'kaiming_normal': (lambda shape: torch.randn(*shape), lambda fi, fo: np.sqrt(1 / fi)),
+}
+
+
 def weight_init(shape, mode, fan_in, fan_out):
-    """Initialisers of networks.py:19-24 (same expressions => same bits for a given generator state)."""
-    if mode == 'xavier_uniform':
-        return np.sqrt(6 / (fan_in + fan_out)) * (torch.rand(*shape) * 2 - 1)
-    if mode == 'xavier_normal':
-        return np.sqrt(2 / (fan_in + fan_out)) * torch.randn(*shape)
-    if mode == 'kaiming_uniform':
-        return np.sqrt(3 / fan_in) * (torch.rand(*shape) * 2 - 1)
-    if mode == 'kaiming_normal':
-        return np.sqrt(1 / fan_in) * torch.randn(*shape)
-    raise ValueError(f'Invalid init mode "{mode}"')
+    if mode not in _INIT_MODES:
+        raise ValueError(f'Invalid init mode "{mode}"')
+    draw, gain = _INIT_MODES[mode]
+    return gain(fan_in, fan_out) * draw(shape)
 
 
 class Linear(torch.nn.Module):
@@ -180,22 +185,30 @@ class UNetBlock(torch.nn.Module):
         if self.num_heads and out_channels != self.num_heads * 64:
             raise NotImplementedError("attention head dim is fixed at 64 (channels_per_head=64, networks.py:393)")
 
-        self.norm0 = GroupNorm(num_channels=in_channels, eps=eps)
-        self.conv0 = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel=3, up=up, down=down,
-                            resample_filter=resample_filter, **init)
-        self.affine = Linear(in_features=emb_channels, out_features=out_channels * 2, **init)
-        self.norm1 = GroupNorm(num_channels=out_channels, eps=eps)
-        self.conv1 = Conv2d(in_channels=out_channels, out_channels=out_channels, kernel=3, **init_zero)
-        self.skip = None
-        if out_channels != in_channels or up or down:
-            kernel = 1 if resample_proj or out_channels != in_channels else 0
-            self.skip = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel=kernel, up=up, down=down,
-                               resample_filter=resample_filter, **init)
+        # Sub-modules in the reference's registration order (it is also the order their parameters are drawn in):
+        # norm0, conv0, affine, norm1, conv1, [skip], [norm2, qkv, proj] (networks.py:148-164).
+        resample = dict(up=up, down=down, resample_filter=resample_filter)
+        cin, cout = in_channels, out_channels
+        needs_skip = cout != cin or up or down
+        skip_kernel = 1 if (resample_proj or cout != cin) else 0  # 0: weight-less resampling only
+        layers = [
+            ("norm0", lambda: GroupNorm(num_channels=cin, eps=eps)),
+            ("conv0", lambda: Conv2d(in_channels=cin, out_channels=cout, kernel=3, **resample, **init)),
+            ("affine", lambda: Linear(in_features=emb_channels, out_features=cout * 2, **init)),
+            ("norm1", lambda: GroupNorm(num_channels=cout, eps=eps)),
+            ("conv1", lambda: Conv2d(in_channels=cout, out_channels=cout, kernel=3, **init_zero)),
+            ("skip", (lambda: Conv2d(in_channels=cin, out_channels=cout, kernel=skip_kernel, **resample, **init))
+             if needs_skip else None),
+        ]
         if self.num_heads:
-            self.norm2 = GroupNorm(num_channels=out_channels, eps=eps)
-            self.qkv = Conv2d(in_channels=out_channels, out_channels=out_channels * 3, kernel=1,
-                              **(init_attn if init_attn is not None else init))
-            self.proj = Conv2d(in_channels=out_channels, out_channels=out_channels, kernel=1, **init_zero)
+            layers += [
+                ("norm2", lambda: GroupNorm(num_channels=cout, eps=eps)),
+                ("qkv", lambda: Conv2d(in_channels=cout, out_channels=cout * 3, kernel=1,
+                                       **(init_attn if init_attn is not None else init))),
+                ("proj", lambda: Conv2d(in_channels=cout, out_channels=cout, kernel=1, **init_zero)),
+            ]
+        for name, make in layers:
+            setattr(self, name, make() if make is not None else None)
 
     def forward(self, x, emb, params=None):
         """networks.py:166-187 as 6 (+4 with attention) kernels:
@@ -273,6 +286,41 @@ class PositionalEmbedding(torch.nn.Module):
         return ops.pos_embedding(x.to(torch.float32).reshape(-1).contiguous(), self.num_channels, self.max_positions)
 
 
+def adm_unet_plan(img_resolution, in_channels, model_channels, channel_mult, num_blocks, attn_resolutions):
+    """Topology of the ADM UNet the reference builds (networks.py:402-433) as two ordered lists of
+    ``(name, in_channels, out_channels, kind, attention)`` with kind in {"conv", "block", "down", "up"}, plus the channel
+    count that reaches the output norm.  Names carry the NOMINAL resolution ``img_resolution >> level`` (the state-dict
+    contract, SURVEY §0.8).  Encoder: a 3x3 stem, then per level an optional down block and ``num_blocks`` blocks;
+    decoder, deepest level first: two bottleneck blocks (the first with attention) or an up block, then
+    ``num_blocks + 1`` blocks, each consuming one encoder output as a skip connection (its channels are added to the
+    block's input)."""
+    levels = [(img_resolution >> lv, model_channels * mult) for lv, mult in enumerate(channel_mult)]
+    enc, ch = [], in_channels
+    for lv, (res, width) in enumerate(levels):
+        tag = f"{res}x{res}"
+        if lv == 0:
+            enc.append((f"{tag}_conv", ch, width, "conv", False))
+            ch = width
+        else:
+            enc.append((f"{tag}_down", ch, ch, "down", False))
+        for i in range(num_blocks):
+            enc.append((f"{tag}_block{i}", ch, width, "block", res in attn_resolutions))
+            ch = width
+    skip_widths = [e[2] for e in enc]
+    dec = []
+    for lv, (res, width) in reversed(list(enumerate(levels))):
+        tag = f"{res}x{res}"
+        if lv == len(levels) - 1:
+            dec.append((f"{tag}_in0", ch, ch, "block", True))
+            dec.append((f"{tag}_in1", ch, ch, "block", False))
+        else:
+            dec.append((f"{tag}_up", ch, ch, "up", False))
+        for i in range(num_blocks + 1):
+            dec.append((f"{tag}_block{i}", ch + skip_widths.pop(), width, "block", res in attn_resolutions))
+            ch = width
+    return enc, dec, ch
+
+
 class DhariwalUNet(torch.nn.Module):
     def __init__(self, img_resolution, in_channels, out_channels, label_dim=0, augment_dim=0, model_channels=192,
                  channel_mult=[1, 2, 3, 4], channel_mult_emb=4, num_blocks=3, attn_resolutions=[32, 16, 8],
@@ -293,40 +341,21 @@ class DhariwalUNet(torch.nn.Module):
         self.map_layer1 = Linear(in_features=emb_channels, out_features=emb_channels, **init)
         self.map_label = None
 
+        # The topology comes from a plan (adm_unet_plan): entries are instantiated in plan order, which is the
+        # reference's registration order and therefore its parameter-draw order and its state-dict key order.
+        enc_plan, dec_plan, final_channels = adm_unet_plan(img_resolution, in_channels, model_channels, channel_mult,
+                                                           num_blocks, attn_resolutions)
         self.enc = torch.nn.ModuleDict()
-        cout = in_channels
-        for level, mult in enumerate(channel_mult):
-            res = img_resolution >> level
-            if level == 0:
-                cin = cout
-                cout = model_channels * mult
-                self.enc[f'{res}x{res}_conv'] = Conv2d(in_channels=cin, out_channels=cout, kernel=3, **init)
-            else:
-                self.enc[f'{res}x{res}_down'] = UNetBlock(in_channels=cout, out_channels=cout, down=True,
-                                                          **block_kwargs)
-            for idx in range(num_blocks):
-                cin = cout
-                cout = model_channels * mult
-                self.enc[f'{res}x{res}_block{idx}'] = UNetBlock(in_channels=cin, out_channels=cout,
-                                                                attention=(res in attn_resolutions), **block_kwargs)
-        skips = [block.out_channels for block in self.enc.values()]
-
         self.dec = torch.nn.ModuleDict()
-        for level, mult in reversed(list(enumerate(channel_mult))):
-            res = img_resolution >> level
-            if level == len(channel_mult) - 1:
-                self.dec[f'{res}x{res}_in0'] = UNetBlock(in_channels=cout, out_channels=cout, attention=True,
-                                                         **block_kwargs)
-                self.dec[f'{res}x{res}_in1'] = UNetBlock(in_channels=cout, out_channels=cout, **block_kwargs)
-            else:
-                self.dec[f'{res}x{res}_up'] = UNetBlock(in_channels=cout, out_channels=cout, up=True, **block_kwargs)
-            for idx in range(num_blocks + 1):
-                cin = cout + skips.pop()
-                cout = model_channels * mult
-                self.dec[f'{res}x{res}_block{idx}'] = UNetBlock(in_channels=cin, out_channels=cout,
-                                                                attention=(res in attn_resolutions), **block_kwargs)
-        self.out_norm = GroupNorm(num_channels=cout)
-        self.out_conv = Conv2d(in_channels=cout, out_channels=out_channels, kernel=3, **init_zero)
+        for holder, plan in ((self.enc, enc_plan), (self.dec, dec_plan)):
+            for name, cin, cout, kind, attention in plan:
+                if kind == "conv":
+                    holder[name] = Conv2d(in_channels=cin, out_channels=cout, kernel=3, **init)
+                else:
+                    holder[name] = UNetBlock(in_channels=cin, out_channels=cout, up=(kind == "up"),
+                                             down=(kind == "down"), attention=attention, **block_kwargs)
+        self.out_norm = GroupNorm(num_channels=final_channels)
+        self.out_conv = Conv2d(in_channels=final_channels, out_channels=out_channels, kernel=3, **init_zero)
         # dropout stream ids depend only on the position inside this network (same model => same masks per step)
         for i, mod in enumerate(m for m in self.modules() if isinstance(m, GroupNorm)):
             mod._rng_id = i + 1

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r2prof
 mkdir -p $O
 if [ "$1" != "noprof-bench" ]; then
-timeout -k 10 400 python3 bench.py --steps 3 --warmup 1 > $O/bench_default.json 2> $O/bench_default.err || { echo "bench failed"; tail -5 $O/bench_default.err; exit 1; }
+timeout -k 10 400 python3 bench.py --steps 3 --warmup 1 --launch-table $O/launch_table_B1_b4096.csv > $O/bench_default.json 2> $O/bench_default.err || { echo "bench failed"; tail -5 $O/bench_default.err; exit 1; }
 echo "bench ok"; cut -c1-300 $O/bench_default.json
 fi
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval_stats -o eval -- python3 tools/eval_once.py 4096 B1_weather96 3 > $O/eval_stats.log 2>&1 || { echo "eval stats failed"; tail -5 $O/eval_stats.log; exit 1; }
