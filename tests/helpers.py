@@ -94,3 +94,10 @@ def fullsize_inputs(name):
 def tensor_sha(t):
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()[:16]
+
+
+def assert_close(a, b, tol, what=""):
+    """The path's bar in two measures at once: max|a-b|/max|b| and the RMS-relative error (one large element cannot
+    hide the error of the small ones in the second)."""
+    e, r = rel_err(a, b), rms_rel_err(a, b)
+    assert e < tol and r < tol, (what, "max/max %.3e rms %.3e (bar %.1e)" % (e, r, tol))

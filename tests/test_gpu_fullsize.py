@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import rel_err
+from tests.helpers import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -32,7 +32,7 @@ def test_fullsize_denoiser_is_batch_independent_and_kernel_families_agree(b1):
     with torch.no_grad():
         whole = model.net(x, sig)
         parts = torch.cat([model.net(x[:5], sig), model.net(x[5:16], sig), model.net(x[16:], sig)])
-        assert rel_err(parts.cpu().numpy(), whole.cpu().numpy()) < 1e-5
+        assert_close(parts.cpu().numpy(), whole.cpu().numpy(), 1e-5)
         imageni2r_amd.set_conv_math("f32")
         try:
             exact = model.net(x[:16], sig)
@@ -40,7 +40,7 @@ def test_fullsize_denoiser_is_batch_independent_and_kernel_families_agree(b1):
             imageni2r_amd.set_conv_math("f16x2")
         assert rel_err(whole[:16].cpu().numpy(), exact.cpu().numpy()) < 1e-4  # the path's bar, through 100+ layers
         per_sample_sigma = torch.full((16,), 2.5, device=DEV)
-        assert rel_err(model.net(x[:16], per_sample_sigma).cpu().numpy(), whole[:16].cpu().numpy()) < 1e-5
+        assert_close(model.net(x[:16], per_sample_sigma).cpu().numpy(), whole[:16].cpu().numpy(), 1e-5)
 
 
 def test_fullsize_loss_is_a_mean_gradients_average_over_halves(b1):
@@ -88,7 +88,7 @@ def test_fullsize_sampler_is_deterministic_and_series_independent(b1):
     assert out.dtype == torch.float64 and torch.isfinite(out).all()
     assert torch.equal(out, proc.sample(xT))                       # graph replay: bit-identical
     halves = torch.cat([proc.sample(xT[:8]), proc.sample(xT[8:])])  # other batch size, other graphs
-    assert rel_err(halves.cpu().numpy(), out.cpu().numpy()) < 1e-4
+    assert_close(halves.cpu().numpy(), out.cpu().numpy(), 1e-4)
     model.ts_img.img_shape = (16, args.input_channels, args.embedding, S - 1)
     ts = model.img_to_ts(out)
     assert tuple(ts.shape) == (16, args.seq_len, args.input_channels) and torch.isfinite(ts).all()

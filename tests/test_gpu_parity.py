@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import as_f32, as_f64, golden_meta, load_golden, probe_vec, rel_err, tiny_args
+from tests.helpers import assert_close, as_f32, as_f64, golden_meta, load_golden, probe_vec, rel_err, tiny_args
 from oracle import i2r_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -70,7 +70,7 @@ def test_delay_embedding_full_size_roundtrip_and_backward(ops):
         for c in range(cols):
             if idx[r, c] >= 0:
                 ref[:, idx[r, c], :] += dimg[:, :, r, c].numpy()
-    assert rel_err(dts, ref) < 1e-6
+    assert_close(dts, ref, 1e-6)
 
 
 def test_delay_edge_cases(ops):
@@ -94,7 +94,7 @@ def test_delay_edge_cases(ops):
 def test_pos_embedding(ops):
     g = load_golden("g3_layers.npz")
     out = ops.pos_embedding(cu(g["pe_in"]), 128).cpu().numpy()
-    assert rel_err(out, g["pe_out"]) < 1e-6
+    assert_close(out, g["pe_out"], 1e-6)
 
 
 @pytest.mark.parametrize("C,H", [(64, 8), (128, 4), (96, 2)])
@@ -104,11 +104,11 @@ def test_groupnorm_golden(ops, C, H):
     x, w, b, dy = cu(g[t + "_x"]), cu(g[t + "_w"]), cu(g[t + "_b"]), cu(g[t + "_dy"])
     G = min(32, C // 4)
     y, mean, rstd = ops.groupnorm_fwd(x, w, b, G, 1e-5, save_stats=True)
-    assert rel_err(y.cpu().numpy(), g[t + "_y"]) < TOL
+    assert_close(y.cpu().numpy(), g[t + "_y"], TOL)
     dx, dw, db, _ = ops.groupnorm_bwd(x, w, b, None, mean, rstd, dy, G, False)
-    assert rel_err(dx.cpu().numpy(), g[t + "_dx"]) < TOL
-    assert rel_err(dw.cpu().numpy(), g[t + "_dw"]) < TOL
-    assert rel_err(db.cpu().numpy(), g[t + "_db"]) < TOL
+    assert_close(dx.cpu().numpy(), g[t + "_dx"], TOL)
+    assert_close(dw.cpu().numpy(), g[t + "_dw"], TOL)
+    assert_close(db.cpu().numpy(), g[t + "_db"], TOL)
 
 
 def test_groupnorm_fused_modes_vs_oracle(ops):
@@ -124,20 +124,20 @@ def test_groupnorm_fused_modes_vs_oracle(ops):
     ref.backward(dy)
     y, mean, rstd = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5,
                                       ss=cu(ss.detach().numpy()), act=True, save_stats=True)
-    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), TOL)
     dx, dw, db, dss = ops.groupnorm_bwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), cu(ss.detach().numpy()), mean,
                                         rstd, cu(dy.numpy()), 32, True)
-    assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
-    assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
-    assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
-    assert rel_err(dss.cpu().numpy(), ss.grad.numpy()) < TOL
+    assert_close(dx.cpu().numpy(), xr.grad.numpy(), TOL)
+    assert_close(dw.cpu().numpy(), wr.grad.numpy(), TOL)
+    assert_close(db.cpu().numpy(), br.grad.numpy(), TOL)
+    assert_close(dss.cpu().numpy(), ss.grad.numpy(), TOL)
     # broadcast (batch-1) modulation as used by the sampler + SiLU-only mode
     y1, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5,
                                  ss=cu(ss.detach().numpy()[:1]), act=True)
     ref1 = torch.nn.functional.silu(ss[:1, C:, None, None] + O.group_norm(x, w, b) * (ss[:1, :C, None, None] + 1))
-    assert rel_err(y1.cpu().numpy(), ref1.detach().numpy()) < TOL
+    assert_close(y1.cpu().numpy(), ref1.detach().numpy(), TOL)
     y2, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), 32, 1e-5, act=True)
-    assert rel_err(y2.cpu().numpy(), torch.nn.functional.silu(O.group_norm(x, w, b)).numpy()) < TOL
+    assert_close(y2.cpu().numpy(), torch.nn.functional.silu(O.group_norm(x, w, b)).numpy(), TOL)
 
 
 def test_groupnorm_dropout_is_consistent(ops):
@@ -160,7 +160,7 @@ def test_groupnorm_dropout_is_consistent(ops):
     dy = torch.ones_like(xd)
     dxa, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy * keep.float() / (1 - p), 32, False)
     dxb, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy, 32, False, drop_p=p, seed=123, offset=7)
-    assert rel_err(dxb.cpu().numpy(), dxa.cpu().numpy()) < 1e-5
+    assert_close(dxb.cpu().numpy(), dxa.cpu().numpy(), 1e-5)
 
 
 @pytest.mark.parametrize("name", ["c3", "c1", "c3up", "c3down", "k0up", "k0down", "c3_1x1sp"])
@@ -179,11 +179,11 @@ def test_conv_golden(ops, name):
     conv = conv.to(DEV)
     y = conv(x)
     y.backward(cu(g[t + "_dy"]))
-    assert rel_err(y.detach().cpu().numpy(), g[t + "_y"]) < TOL
-    assert rel_err(x.grad.cpu().numpy(), g[t + "_dx"]) < TOL
+    assert_close(y.detach().cpu().numpy(), g[t + "_y"], TOL)
+    assert_close(x.grad.cpu().numpy(), g[t + "_dx"], TOL)
     if has_w:
-        assert rel_err(conv.weight.grad.cpu().numpy(), g[t + "_dw"]) < TOL
-        assert rel_err(conv.bias.grad.cpu().numpy(), g[t + "_db"]) < TOL
+        assert_close(conv.weight.grad.cpu().numpy(), g[t + "_dw"], TOL)
+        assert_close(conv.bias.grad.cpu().numpy(), g[t + "_db"], TOL)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 128, 128, 16, 3), (2, 384, 256, 8, 3), (3, 1024, 512, 2, 3),
@@ -203,12 +203,12 @@ def test_conv_shapes_vs_oracle(ops, B, Cin, Cout, H, k):
     ref = torch.nn.functional.conv2d(xr, wr, br, padding=k // 2) + res
     ref.backward(dy)
     y = ops.conv2d_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), cu(res.numpy()))
-    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), TOL)
     dx = ops.conv2d_dgrad(cu(dy.numpy()), cu(w.numpy()))
-    assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
+    assert_close(dx.cpu().numpy(), xr.grad.numpy(), TOL)
     dw, db = ops.conv2d_wgrad(cu(x.numpy()), cu(dy.numpy()), k)
-    assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
-    assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+    assert_close(dw.cpu().numpy(), wr.grad.numpy(), TOL)
+    assert_close(db.cpu().numpy(), br.grad.numpy(), TOL)
 
 
 def test_conv_c_abi_convenience_entry_points(ops):
@@ -235,13 +235,13 @@ def test_conv_c_abi_convenience_entry_points(ops):
         out = torch.empty(B, Cout, H, H, device=DEV)
         _lib.call("i2r_conv2d_fwd_f32", vp(xd), vp(wd), vp(bd), None, vp(out), vp(ws), pf + extra, B, Cin, H, H, Cout,
                   k, st)
-        assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+        assert_close(out.cpu().numpy(), ref.numpy(), TOL)
     pfd = _lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, 1)
     skd = _lib.query("i2r_conv2d_splitk_floats", B, Cout, H, H, Cin, k)
     ws = torch.empty(pfd + skd, device=DEV)
     dx = torch.empty(B, Cin, H, H, device=DEV)
     _lib.call("i2r_conv2d_dgrad_f32", vp(dyd), vp(wd), vp(ws), pfd + skd, vp(dx), B, Cin, H, H, Cout, k, st)
-    assert rel_err(dx.cpu().numpy(), ref_dx.numpy()) < TOL
+    assert_close(dx.cpu().numpy(), ref_dx.numpy(), TOL)
     with pytest.raises(_lib.I2RError):  # workspace too small for the packed weights -> loud error
         _lib.call("i2r_conv2d_fwd_f32", vp(xd), vp(wd), vp(bd), None, vp(out), vp(ws), 16, B, Cin, H, H, Cout, k, st)
 
@@ -252,9 +252,9 @@ def test_attention_golden(ops, heads, C, H):
     t = f"attn_h{heads}_C{C}_H{H}"
     qkv = cu(g[t + "_qkv"])
     a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
-    assert rel_err(a.cpu().numpy(), g[t + "_a"]) < TOL
+    assert_close(a.cpu().numpy(), g[t + "_a"], TOL)
     dqkv = ops.attention_bwd(qkv, a, lse, cu(g[t + "_da"]), heads)
-    assert rel_err(dqkv.cpu().numpy(), g[t + "_dqkv"]) < TOL
+    assert_close(dqkv.cpu().numpy(), g[t + "_dqkv"], TOL)
 
 
 @pytest.mark.parametrize("B,heads,H", [(2, 2, 16), (1, 4, 32), (3, 8, 2), (2, 4, 4), (1, 2, 8)])
@@ -268,9 +268,9 @@ def test_attention_shapes_vs_oracle(ops, B, heads, H):
     ref.backward(da)
     q = cu(qkv.detach().numpy())
     a, lse = ops.attention_fwd(q, heads, save_lse=True)
-    assert rel_err(a.cpu().numpy(), ref.detach().numpy()) < TOL
+    assert_close(a.cpu().numpy(), ref.detach().numpy(), TOL)
     dqkv = ops.attention_bwd(q, a, lse, cu(da.numpy()), heads)
-    assert rel_err(dqkv.cpu().numpy(), qkv.grad.numpy()) < TOL
+    assert_close(dqkv.cpu().numpy(), qkv.grad.numpy(), TOL)
 
 
 def test_attention_large_scores_online_softmax(ops):
@@ -281,7 +281,7 @@ def test_attention_large_scores_online_softmax(ops):
     qkv.view(B, 64, 3, H * H)[:, :, 1, 200:] *= 6.0  # keys in late tiles dominate
     ref = O.attention(qkv, heads)
     a, _ = ops.attention_fwd(cu(qkv.numpy()), heads)
-    assert rel_err(a.cpu().numpy(), ref.numpy()) < TOL
+    assert_close(a.cpu().numpy(), ref.numpy(), TOL)
 
 
 def test_linear_vs_oracle(ops):
@@ -298,10 +298,10 @@ def test_linear_vs_oracle(ops):
             cu(b.detach().numpy()).requires_grad_(True)
         y = ops.LinearFn.apply(xd, wd, bd, act)
         y.backward(cu(dy.numpy()))
-        assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < TOL
-        assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < TOL
-        assert rel_err(wd.grad.cpu().numpy(), w.grad.numpy()) < TOL
-        assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < TOL
+        assert_close(y.detach().cpu().numpy(), ref.detach().numpy(), TOL)
+        assert_close(xd.grad.cpu().numpy(), x.grad.numpy(), TOL)
+        assert_close(wd.grad.cpu().numpy(), w.grad.numpy(), TOL)
+        assert_close(bd.grad.cpu().numpy(), b.grad.numpy(), TOL)
 
 
 @pytest.mark.parametrize("name,cin,cout,kw", [("plain", 16, 16, {}), ("down", 16, 16, dict(down=True)),
@@ -319,10 +319,10 @@ def test_unet_block_golden(ops, name, cin, cout, kw):
     x = cu(g[t + "_x"]).requires_grad_(True)
     y = blk(x, cu(g[t + "_emb"]))
     y.backward(cu(g[t + "_dy"]))
-    assert rel_err(y.detach().cpu().numpy(), g[t + "_y"]) < TOL
-    assert rel_err(x.grad.cpu().numpy(), g[t + "_dx"]) < TOL
+    assert_close(y.detach().cpu().numpy(), g[t + "_y"], TOL)
+    assert_close(x.grad.cpu().numpy(), g[t + "_dx"], TOL)
     for k, p in blk.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), g[t + "_g_" + k]) < TOL, k
+        assert_close(p.grad.cpu().numpy(), g[t + "_g_" + k], TOL, k)
 
 
 # ------------------------------------------------------------------------------------------------ net / loss / sampler
@@ -339,10 +339,10 @@ def test_denoiser_golden(tiny_gpu):
     g = load_golden("g4_net.npz")
     with torch.no_grad():
         D = tiny_gpu.net(cu(g["x"]), cu(g["sigma"]))
-        assert rel_err(D.cpu().numpy(), g["D_per_sample"]) < TOL
+        assert_close(D.cpu().numpy(), g["D_per_sample"], TOL)
         D2 = tiny_gpu.net(cu(g["x"]).double(), torch.tensor(1.7, dtype=torch.float64))
         assert D2.dtype == torch.float32
-        assert rel_err(D2.cpu().numpy(), g["D_scalar_sigma"]) < TOL
+        assert_close(D2.cpu().numpy(), g["D_scalar_sigma"], TOL)
 
 
 def test_denoiser_and_sampler_golden_f16_option(tiny_gpu):
@@ -359,11 +359,11 @@ def test_denoiser_and_sampler_golden_f16_option(tiny_gpu):
         assert TOL * 1e-2 < e < 1e-2, e
         out = DiffusionProcess(tiny_args(device=DEV), tiny_gpu.net, (3, 8, 8), use_graph=False).sample(
             torch.from_numpy(g5["xT"]))
-        assert rel_err(out.cpu().numpy(), g5["out"]) < 1e-2
+        assert_close(out.cpu().numpy(), g5["out"], 1e-2)
     finally:
         imageni2r_amd.set_conv_math("f16x2")
     with torch.no_grad():  # and the default path is back
-        assert rel_err(tiny_gpu.net(cu(g["x"]), cu(g["sigma"])).cpu().numpy(), g["D_per_sample"]) < TOL
+        assert_close(tiny_gpu.net(cu(g["x"]), cu(g["sigma"])).cpu().numpy(), g["D_per_sample"], TOL)
 
 
 @pytest.fixture(params=["0", "1"], ids=["fwd_f32", "fwd_f16x2"])
@@ -401,7 +401,7 @@ def test_loss_and_gradients_golden(tiny_gpu, train_fwd):
             assert abs(got[0] - summ[i][0]) <= TOL * scale, k
             assert abs(got[2] - summ[i][2]) <= TOL * scale, k
             if ("grad_full_" + k) in g:
-                assert rel_err(params[k].grad.cpu().numpy(), g["grad_full_" + k]) < TOL, k
+                assert_close(params[k].grad.cpu().numpy(), g["grad_full_" + k], TOL, k)
         # mask=None branch (NaN-derived mask)
         x_img = m.ts_to_img(cu(as_f32(g["loss_ts"])))
         loss2, _ = m.loss_fn_irregular(x_img, None)
@@ -445,7 +445,7 @@ def test_sampler_golden(tiny_gpu):
         proc = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8), use_graph=use_graph)
         out = proc.sampling(sampling_number=2, xT=torch.from_numpy(g["xT"]))
         assert out.dtype == torch.float64 and tuple(out.shape) == (2, 3, 8, 8)
-        assert rel_err(out.cpu().numpy(), g["out"]) < TOL, use_graph
+        assert_close(out.cpu().numpy(), g["out"], TOL, use_graph)
         if use_graph:  # replay gives the same answer again, and a new xT gives a different one
             out2 = proc.sampling(sampling_number=2, xT=torch.from_numpy(g["xT"]))
             assert torch.equal(out, out2)
@@ -454,7 +454,7 @@ def test_sampler_golden(tiny_gpu):
     tiny_gpu.ts_img.img_shape = (2, 3, 8, 7)
     ts = tiny_gpu.img_to_ts(out)
     ref_ts = as_f32(g["ts_out"])
-    assert rel_err(ts.cpu().numpy(), ref_ts) < TOL
+    assert_close(ts.cpu().numpy(), ref_ts, TOL)
 
 
 def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
@@ -471,11 +471,11 @@ def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
     out = two.sample(xT)
     halves = [k for k in two._graphs if k[0] == (4, 3, 8, 8)]  # (the graph cache lives on the net, shared by both)
     assert len(halves) == 2 and tuple(out.shape) == (8, 3, 8, 8)
-    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert_close(out.cpu().numpy(), ref.cpu().numpy(), 1e-5)
     assert torch.equal(out, two.sample(xT))
     g = load_golden("g5_sampler.npz")  # and the golden pair still comes out right through the split path
     two.dual_stream_min = 2
-    assert rel_err(two.sample(torch.from_numpy(g["xT"])).cpu().numpy(), g["out"]) < TOL
+    assert_close(two.sample(torch.from_numpy(g["xT"])).cpu().numpy(), g["out"], TOL)
 
 
 def test_sampler_bulk_request_is_sampled_in_pieces(tiny_gpu):
@@ -492,7 +492,7 @@ def test_sampler_bulk_request_is_sampled_in_pieces(tiny_gpu):
         proc.dual_stream_min, proc.max_graph_batch = dual_min, cap
         out = proc.sample(xT)
         assert out.dtype == torch.float64 and tuple(out.shape) == (11, 3, 8, 8)
-        assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (dual_min, cap)
+        assert_close(out.cpu().numpy(), ref.cpu().numpy(), 1e-5, (dual_min, cap))
     assert max(k[0][0] for k in tiny_gpu.net._i2r_sampler_graphs if k[0][1:] == (3, 8, 8)) == 11  # only `one` took all 11
 
 

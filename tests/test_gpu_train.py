@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import rel_err, tiny_args
+from tests.helpers import assert_close, rel_err, tiny_args
 from oracle import i2r_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -49,14 +49,14 @@ def test_groupnorm_register_kernels_all_geometries(ops, B, C, H):
         ssd = cu(ss.detach().numpy()) if use_ss else None
         y, mean, rstd = ops.groupnorm_fwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), G, 1e-5, ss=ssd, act=act,
                                           save_stats=True)
-        assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < TOL
+        assert_close(y.cpu().numpy(), ref.detach().numpy(), TOL)
         dx, dw, db, dss = ops.groupnorm_bwd(cu(x.numpy()), cu(w.numpy()), cu(b.numpy()), ssd, mean, rstd,
                                             cu(dy.numpy()), G, act)
-        assert rel_err(dx.cpu().numpy(), xr.grad.numpy()) < TOL
-        assert rel_err(dw.cpu().numpy(), wr.grad.numpy()) < TOL
-        assert rel_err(db.cpu().numpy(), br.grad.numpy()) < TOL
+        assert_close(dx.cpu().numpy(), xr.grad.numpy(), TOL)
+        assert_close(dw.cpu().numpy(), wr.grad.numpy(), TOL)
+        assert_close(db.cpu().numpy(), br.grad.numpy(), TOL)
         if use_ss:
-            assert rel_err(dss.cpu().numpy(), ssr.grad.numpy()) < TOL
+            assert_close(dss.cpu().numpy(), ssr.grad.numpy(), TOL)
 
 
 def test_groupnorm_dropout_device_step(ops):
@@ -75,7 +75,7 @@ def test_groupnorm_dropout_device_step(ops):
     dy = torch.ones_like(xd)
     dxa, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy * keep.float() / (1 - p), 32, False)
     dxb, *_ = ops.groupnorm_bwd(xd, wd, bd, None, mean, rstd, dy, 32, False, drop_p=p, seed=9, offset=3, step=ctr)
-    assert rel_err(dxb.cpu().numpy(), dxa.cpu().numpy()) < 1e-5
+    assert_close(dxb.cpu().numpy(), dxa.cpu().numpy(), 1e-5)
     ops.counter_add(ctr, 1)
     assert int(ctr.item()) == 1
     yc, _, _ = ops.groupnorm_fwd(xd, wd, bd, 32, 1e-5, drop_p=p, seed=9, offset=3, step=ctr)
@@ -100,7 +100,7 @@ def test_conv_split_f16_vs_oracle(ops, B, Cin, Cout, H, k):
     ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + res.double()
     wd = cu(w.numpy())
     y = ops.conv2d_fwd_h2(cu(x.numpy()), tuple(w.shape), ops.conv2d_pack_h2(wd), cu(b.numpy()), cu(res.numpy()))
-    assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-6
+    assert_close(y.cpu().numpy(), ref.numpy(), 2e-6)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,k", [(3, 128, 128, 16, 3), (2, 256, 384, 8, 1), (5, 96, 160, 4, 3),
@@ -122,7 +122,7 @@ def test_groupnorm_split_out_feeds_split_conv(ops, B, Cin, Cout, H, k):
     ysp, _, _ = ops.groupnorm_fwd(cu(x.numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, ss=cu(ss.numpy()), act=True,
                                   split_out=True)
     y = ops.conv2d_fwd_h2(ysp, tuple(w.shape), ops.conv2d_pack_h2(cu(w.numpy())), cu(b.numpy()), None, x_split=True)
-    assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-6
+    assert_close(y.cpu().numpy(), ref.numpy(), 5e-6)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(3, 128, 128, 16), (5, 96, 160, 4), (2, 1024, 512, 2), (2, 128, 12, 16),
@@ -149,14 +149,14 @@ def test_conv_f16_single_term_path(ops, B, Cin, Cout, H):
         y = ops.conv2d_fwd_h2(ysp, tuple(w.shape), wp, cu(b.numpy()), cu(res.numpy()), x_split=True)
     finally:
         imageni2r_amd.set_conv_math("f16x2")
-    assert rel_err(full.cpu().numpy(), ref.numpy()) < 5e-6
+    assert_close(full.cpu().numpy(), ref.numpy(), 5e-6)
     e = rel_err(y.cpu().numpy(), ref.numpy())
     assert 1e-6 < e < 2e-3, e  # really the reduced product, and well inside 1e-2
     # the rounded operands: hi halves as the GroupNorm kernel stored them, weights as packed (scaled by 64, see the kernel)
     x_hi = (ysp.view(torch.int32) & 0xFFFF).to(torch.int16).view(torch.float16).double().cpu()
     w_hi = (w * 64.0).half().double() / 64.0
     ref_hi = torch.nn.functional.conv2d(x_hi, w_hi, b.double(), padding=1) + res.double()
-    assert rel_err(y.cpu().numpy(), ref_hi.numpy()) < 2e-6
+    assert_close(y.cpu().numpy(), ref_hi.numpy(), 2e-6)
 
 
 @pytest.mark.parametrize("B,heads,H", [(2, 2, 16), (1, 4, 32), (3, 4, 8), (2, 8, 8), (1, 2, 8)])
@@ -174,7 +174,7 @@ def test_attention_split_f16_vs_oracle(ops, B, heads, H):
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
     _lib.call("i2r_attention_fwd_h2", vp(q), vp(out), B, heads, H * H, 0,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    assert rel_err(out.cpu().numpy(), ref.numpy()) < 5e-6
+    assert_close(out.cpu().numpy(), ref.numpy(), 5e-6)
     a, _ = ops.attention_fwd(q, heads)  # the dispatcher picks the same kernel in f16x2 mode
     assert torch.equal(a, out)
 
@@ -194,9 +194,9 @@ def test_qkv_conv_split_output_feeds_presplit_attention(ops, B, C, H):
     xd, bd = cu(x.numpy()), cu(b.numpy())
     qkv_sp = ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, bd, None, qkv_out=True)
     a_sp, _ = ops.attention_fwd(qkv_sp, heads, presplit=True)
-    assert rel_err(a_sp.cpu().numpy(), ref.numpy()) < 5e-6
+    assert_close(a_sp.cpu().numpy(), ref.numpy(), 5e-6)
     a_plain, _ = ops.attention_fwd(ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, bd, None), heads)
-    assert rel_err(a_sp.cpu().numpy(), a_plain.cpu().numpy()) < 5e-6
+    assert_close(a_sp.cpu().numpy(), a_plain.cpu().numpy(), 5e-6)
 
 
 @pytest.mark.parametrize("B,C1,C2,H,Cout", [(3, 256, 128, 8, 256), (2, 512, 512, 2, 512), (2, 256, 256, 4, 256),
@@ -219,14 +219,14 @@ def test_concat_free_groupnorm_and_skip_conv(ops, B, C1, C2, H, Cout):
     ref_c = torch.nn.functional.conv2d(cat, w.double(), bias.double()) + res.double()
     a, b = cu(x1.numpy()), cu(x2.numpy())
     y = ops.groupnorm_cat_fwd(a, b, cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True)
-    assert rel_err(y.cpu().numpy(), ref_n.numpy()) < 5e-6
+    assert_close(y.cpu().numpy(), ref_n.numpy(), 5e-6)
     ysp = ops.groupnorm_cat_fwd(a, b, cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True, split_out=True)
     y1, _, _ = ops.groupnorm_fwd(cu(cat.float().numpy()), cu(gw.numpy()), cu(gb.numpy()), G, 1e-5, act=True,
                                  split_out=True)
     assert torch.equal(ysp.view(torch.int32), y1.view(torch.int32))  # same bits as the single-tensor kernel
     wd = cu(w.numpy())
     c = ops.conv1x1_cat_fwd_h2(a, b, tuple(w.shape), ops.conv2d_pack_h2(wd), cu(bias.numpy()), cu(res.numpy()))
-    assert rel_err(c.cpu().numpy(), ref_c.numpy()) < 2e-6
+    assert_close(c.cpu().numpy(), ref_c.numpy(), 2e-6)
 
 
 def _ref_tail(params, grads, state, shadows, n_upd, lr, wd, max_norm, warmup, steps):
@@ -281,8 +281,8 @@ def test_fused_adamw_clip_ema_vs_torch():
     assert int(m.model_ema.num_updates.item()) == steps
     bufs = dict(m.model_ema.named_buffers())
     for k, p, rp, rs in zip(names, m.net.parameters(), ref_p, ref_s):
-        assert rel_err(p.detach().cpu().numpy(), rp.numpy()) < 2e-6, k
-        assert rel_err(bufs[m.model_ema.m_name2s_name[k]].cpu().numpy(), rs.numpy()) < 2e-6, k
+        assert_close(p.detach().cpu().numpy(), rp.numpy(), 2e-6, k)
+        assert_close(bufs[m.model_ema.m_name2s_name[k]].cpu().numpy(), rs.numpy(), 2e-6, k)
     sd = opt.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == steps
 
@@ -317,7 +317,7 @@ def test_graphed_train_step_matches_eager():
     for a, b in zip(le, lg):
         assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
     for a, b in zip(pe, pg):  # Adam's sign-like first steps amplify the last-bit noise of the atomics in wgrad
-        assert rel_err(b.numpy(), a.numpy()) < 5e-3
+        assert_close(b.numpy(), a.numpy(), 5e-3)
     assert len(set(np.round(lg, 6))) > 1  # noise / sigma draws differ between replays
 
 
@@ -402,7 +402,7 @@ def test_slot_path_gradients_vs_oracle():
         assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
         for k, p in m.net.named_parameters():
             assert p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr(), k
-            assert rel_err(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-4, (rep, k)
+            assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 1e-4, (rep, k))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hl,split", [(3, 128, 128, 8, True), (2, 256, 256, 4, False), (2, 64, 96, 16, True),
@@ -427,11 +427,11 @@ def test_conv_fused_upsample_input_and_residual(ops, B, Cin, Cout, Hl, split):
     ref = torch.nn.functional.conv2d(up(xin), w.double(), b.double(), padding=1) + up(res.double())
     y = ops.conv2d_fwd_h2(xd, tuple(w.shape), wp, cu(b.numpy()), cu(res.numpy()), x_split=split, up_in=True, up_res=True)
     assert tuple(y.shape) == (B, Cout, 2 * Hl, 2 * Hl)
-    assert rel_err(y.cpu().numpy(), ref.numpy()) < 5e-6
+    assert_close(y.cpu().numpy(), ref.numpy(), 5e-6)
     # residual-only upsampling on a plain conv (conv1 of the up block)
     x2 = torch.randn(B, Cout, 2 * Hl, 2 * Hl, generator=gen)
     w2 = torch.randn(Cout, Cout, 3, 3, generator=gen) / np.sqrt(Cout * 9)
     ref2 = torch.nn.functional.conv2d(x2.double(), w2.double(), b.double(), padding=1) + up(res.double())
     y2 = ops.conv2d_fwd_h2(cu(x2.numpy()), tuple(w2.shape), ops.conv2d_pack_h2(cu(w2.numpy())), cu(b.numpy()),
                            cu(res.numpy()), up_res=True)
-    assert rel_err(y2.cpu().numpy(), ref2.numpy()) < 5e-6
+    assert_close(y2.cpu().numpy(), ref2.numpy(), 5e-6)
