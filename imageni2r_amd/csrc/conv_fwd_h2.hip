@@ -44,6 +44,10 @@ struct ConvHParams {
   int ablate;  // tuning only (I2R_H2_ABLATE): 1 = skip the epilogue stores, 2 = skip the main loop
   int up_in;   // 1 (3x3 DPP path): x is (B, Cin, H/2, W/2) and is nearest-upsampled x2 on the fly (Conv2d up=True, :79-81)
   int up_res;  // 1: the residual is (B, Cout, H/2, W/2), nearest-upsampled x2 on the fly (the kernel-0 `skip` of up blocks)
+  const float* in_scale;  // null, or device float[2] = {s, 1/s}, s a power of two (i2r_absmax_pow2_scale_f32): un-split
+                          // inputs are multiplied by s before the f16 split and the result by 1/s -- both exact -- so
+                          // that tensors far below fp16's normal range (gradients: the data-gradient use of this
+                          // kernel, i2r_conv2d_dgrad_h2) keep their 22 significand bits
   int qkv_out; // 1: the output feeds i2r_attention_fwd_h2(presplit): q channels (c % 3 == 0) are scaled by I2R_QSCALE and
                // every element is stored as the split pair f16 hi | f16 lo << 16 (the attention kernel then only permutes)
 };
@@ -61,6 +65,17 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
   for (int j = 0; j < 8; ++j) {
     _Float16 h, l;
     f16_split(v[j], h, l);
+    hi[j] = h;
+    lo[j] = l;
+  }
+}
+
+// the same on s * v (s a power of two: exact)
+__device__ __forceinline__ void split8s(const float* v, float s, half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 h, l;
+    f16_split(v[j] * s, h, l);
     hi[j] = h;
     lo[j] = l;
   }
@@ -87,7 +102,8 @@ __device__ __forceinline__ void unpack8(const float* v, half8& hi, half8& lo) {
 // after a store waits for it -- interleaved, the 64 elements become 64 serial load -> wait -> store round trips
 // (measured: 25 us per workgroup, more than the whole main loop of a 1x1 conv).
 __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
-                                            bool nvalid, unsigned pb, unsigned pos, int m0, int h, int ablate) {
+                                            bool nvalid, unsigned pb, unsigned pos, int m0, int h, int ablate,
+                                            float omul) {
   const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
   __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
   const unsigned plane = (unsigned)p.HW * 4;
@@ -127,7 +143,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
-        float v = acc[t][r] * WSCALE_INV + bv[t][r] + rv[t][r];
+        float v = acc[t][r] * omul + bv[t][r] + rv[t][r];
         if (decltype(qkv)::value) {
           if ((cmod + cof) % 3 == 0) v *= I2R_QSCALE;
           v = split_pack(v);
@@ -149,7 +165,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
 // Needs W % 4 == 0 (a position quad inside one image row).  `scratch`: this wave's 32 x 36 floats.
 #define EPI_PITCH 36
 __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
-                                                 long nw, int m0, int lane, float* scratch, int ablate) {
+                                                 long nw, int m0, int lane, float* scratch, int ablate, float omul) {
   const int l31 = lane & 31, h = lane >> 5, cr = lane >> 3, pq = (lane & 7) * 4;
   const long nq = nw + pq;
   const bool qvalid = nq < p.Npos;
@@ -211,7 +227,7 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
       uint4v o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float y = v[e] * WSCALE_INV + bv[q] + rv[q][e];
+        float y = v[e] * omul + bv[q] + rv[q][e];
         if (p.qkv_out) {
           if ((cmod + cof) % 3 == 0) y *= I2R_QSCALE;
           y = split_pack(y);
@@ -374,9 +390,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
         }
     }
   };
+  // input scale (wave-uniform; 1 and exact when there is none): only the un-split path multiplies
+  float s_in = 1.0f, omul = WSCALE_INV;
+  if (!SPLIT && p.in_scale != nullptr) {
+    s_in = p.in_scale[0];
+    omul = WSCALE_INV * p.in_scale[1];
+  }
   auto to_frag = [&](const float* v, half8& hi, half8& lo) {
     if (SPLIT) unpack8(v, hi, lo);
-    else split8(v, hi, lo);
+    else split8s(v, s_in, hi, lo);
   };
 
   const int total_chunks = (KS == 3) ? 3 * p.nCB : p.nCB;
@@ -477,9 +499,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
   if ((p.W & 3) == 0 && !(p.ablate & 8))  // quad form: its LDS patch reuses the (now idle) weight stages
     h2_epilogue_quad(p, acc, outp, direct, n0 + wave * 32, m0, lane,
-                     reinterpret_cast<float*>(smem) + wave * (32 * EPI_PITCH), p.ablate);
+                     reinterpret_cast<float*>(smem) + wave * (32 * EPI_PITCH), p.ablate, omul);
   else
-    h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate);
+    h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate,
+                omul);
 }
 
 // out = sum_z slab[z] + bias + residual
@@ -544,6 +567,47 @@ extern "C" int i2r_conv2d_pack_weight_h2(const float* w, void* wp, int Cout, int
   return i2r_check_launch("pack_weight_h2");
 }
 
+// Packed split weights of the DATA-GRADIENT problem: dx = conv2d(dy, Wd), Wd[ci][co][r][s] = w[co][ci][2-r][2-s]
+// (the transposed, tap-flipped filter; autograd of conv2d w.r.t. its input): the forward layout above with the roles
+// of Cout and Cin swapped -- rows = ci (the output channels of this problem), k runs over (tap, co).
+__global__ void pack_weight_h2_dgrad_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout, int Cin,
+                                            int ks, int nCB, long total) {
+  const int KC = ks == 3 ? 48 : 64;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int k = (int)(i % KC);
+    long t = i / KC;
+    int ci = (int)(t % Cin);      // row of the packed matrix = output channel of the dgrad problem
+    int chunk = (int)(t / Cin);
+    float v = 0.0f;
+    if (ks == 3) {
+      int r = chunk / nCB, cb = chunk % nCB;
+      int s = k / 16, co = cb * 16 + (k % 16);
+      if (co < Cout) v = w[((long)co * Cin + ci) * 9 + (2 - r) * 3 + (2 - s)];
+    } else {
+      int co = chunk * 64 + k;
+      if (co < Cout) v = w[(long)co * Cin + ci];
+    }
+    v *= WSCALE;
+    _Float16 hi, lo;
+    f16_split(v, hi, lo);
+    long base = ((long)chunk * Cin + ci) * 2 * KC;
+    wp[base + k] = hi;
+    wp[base + KC + k] = lo;
+  }
+}
+
+// bytes: i2r_conv2d_packed_h2_bytes(Cin, Cout, ksize) -- the transposed problem's size
+extern "C" int i2r_conv2d_pack_weight_h2_dgrad(const float* w, void* wp, int Cout, int Cin, int ksize,
+                                               i2r_stream_t stream) {
+  I2R_REQUIRE(w && wp && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pack_weight_h2_dgrad: bad argument");
+  long total = (long)h2_chunks(Cout, ksize) * Cin * h2_kc(ksize);
+  int nb = i2r_cdiv(total, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pack_weight_h2_dgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)wp, Cout,
+                     Cin, ksize, h2_ncb(Cout, ksize), total);
+  return i2r_check_launch("pack_weight_h2_dgrad");
+}
+
 // positions per workgroup: 256 (8 waves, one workgroup per CU) once that still gives every CU >= 2 workgroups of work,
 // else 128 (4 waves, two workgroups per CU)
 static int h2_bn(long Npos, int Cout, int ksize) {
@@ -579,13 +643,24 @@ extern "C" long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Co
 
 static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, const float* bias,
                      const float* residual, float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H,
-                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream);
+                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream, const float* in_scale = nullptr);
 
 extern "C" int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual,
                                  float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W,
                                  int Cout, int ksize, int x_is_split, i2r_stream_t stream) {
   return h2_launch(x, nullptr, Cin, wp, bias, residual, out, splitk_ws, splitk_floats, B, Cin, H, W, Cout, ksize,
                    x_is_split, stream);
+}
+
+// Data gradient on the f16x2-split kernel: dx (B, Cin, H, W) = conv2d(dy (B, Cout, H, W), Wd).  `scale`: device
+// float[2] {s, 1/s} from i2r_absmax_pow2_scale_f32(dy): gradients sit far below fp16's normal range; multiplied by the
+// power of two s they are split at full precision, and the result is multiplied back (both exact).
+extern "C" int i2r_conv2d_dgrad_h2(const float* dy, const void* wpd, float* dx, const float* scale, float* splitk_ws,
+                                   long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
+                                   i2r_stream_t stream) {
+  I2R_REQUIRE(scale != nullptr, "conv2d_dgrad_h2: needs the {s, 1/s} pair of i2r_absmax_pow2_scale_f32");
+  return h2_launch(dy, nullptr, Cout, wpd, nullptr, nullptr, dx, splitk_ws, splitk_floats, B, Cout, H, W, Cin, ksize,
+                   0, stream, scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -655,7 +730,7 @@ extern "C" int i2r_conv1x1_cat_fwd_h2(const float* x1, const float* x2, int C1, 
 
 static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, const float* bias,
                      const float* residual, float* out, float* splitk_ws, long splitk_floats, int B, int Cin, int H,
-                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream) {
+                     int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream, const float* in_scale) {
   I2R_REQUIRE(x && wp && out, "conv2d_fwd_h2: null pointer");
   I2R_REQUIRE(ksize == 1 || ksize == 3, "conv2d_fwd_h2: kernel size %d unsupported (1 or 3)", ksize);
   I2R_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d_fwd_h2: non-positive dimension");
@@ -689,6 +764,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   p.qkv_out = qkv_out; p.up_in = up_in; p.up_res = up_res;
+  p.in_scale = in_scale;  // (null on every forward call: the un-split path then multiplies by exactly 1)
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);
   dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);

@@ -398,3 +398,46 @@ extern "C" int i2r_pos_embedding_f32(const float* x, float* out, int B, int num_
                      (hipStream_t)stream, x, out, B, num_channels, (float)max_positions);
   return i2r_check_launch("pos_embedding");
 }
+
+// ------------------------------------------------------------------ power-of-two scale of a tensor (f16x2 dgrad)
+// scale_out = {s, 1/s} with s = 2^(13 - floor(log2 max|x|)): s * x peaks in [2^13, 2^14) -- inside fp16's range with a
+// factor 4 to spare, and everything down to 2^-27 of the peak stays representable.  max|x| = 0, inf or NaN: s = 1 (a
+// non-finite gradient then reaches the optimiser as such and its step is skipped).  `scratch`: one uint32 that is 0 on
+// entry and is left 0 (the bit pattern of a non-negative float orders like the float).
+__global__ void absmax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ scratch) {
+  unsigned m = 0;
+  GRID_STRIDE(i, n) {
+    unsigned b = __builtin_bit_cast(unsigned, x[i]) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(scratch, m);
+}
+__global__ void pow2_scale_kernel(unsigned* __restrict__ scratch, float* __restrict__ scale_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned m = scratch[0];
+  scratch[0] = 0;
+  int e = (int)(m >> 23) - 127;              // floor(log2 max|x|) for normal numbers
+  float s = 1.0f;
+  if (m != 0 && m < 0x7F800000u) {           // finite, non-zero
+    int k = 13 - e;
+    if (k > 100) k = 100;                    // (subnormal or tiny peaks: keep 2^k and 2^-k both normal)
+    if (k < -100) k = -100;
+    s = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+  }
+  scale_out[0] = s;
+  scale_out[1] = 1.0f / s;
+}
+extern "C" int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* scale_out,
+                                         i2r_stream_t stream) {
+  I2R_REQUIRE(x && scratch && scale_out && n > 0, "absmax_pow2_scale: bad argument");
+  int nb = ew_grid(n);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, scale_out);
+  return i2r_check_launch("absmax_pow2_scale");
+}

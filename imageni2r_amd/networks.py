@@ -97,6 +97,15 @@ class Conv2d(torch.nn.Module):
             self._wph_key = key
         return self._wph
 
+    def packed_weight_h2_dgrad(self):
+        """Split-f16 packed copy for the data gradient on the f16x2 kernel (same invalidation rule)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, ops.pack_epoch())
+        if getattr(self, "_wpdh_key", None) != key:
+            self._wpdh = ops.conv2d_pack_h2_dgrad(w.detach())
+            self._wpdh_key = key
+        return self._wpdh
+
     def packed_weight_dgrad(self):
         """Transposed + flipped packed copy for the data gradient, only when a current one exists (made by
         DhariwalUNet.pack_all_weights); otherwise None and backward packs on the fly."""
@@ -130,8 +139,10 @@ class Conv2d(torch.nn.Module):
                                          None if residual is None else ops._c(residual), x_split, out, qkv_out,
                                          False, up_res)
             if torch.is_grad_enabled() and ops.train_fwd_h2(x.shape[0] * x.shape[2] * x.shape[3]):
-                return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, None, self.packed_weight_dgrad(),
-                                          self.packed_weight_h2())
+                bwd_h2 = x.requires_grad and ops.train_bwd_h2(x.shape[0] * x.shape[2] * x.shape[3])
+                return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, None,
+                                          None if bwd_h2 else self.packed_weight_dgrad(), self.packed_weight_h2(),
+                                          self.packed_weight_h2_dgrad() if bwd_h2 else None)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:

@@ -109,6 +109,29 @@ def train_fwd_h2(npos=None) -> bool:
     return npos is not None and npos >= _TRAIN_FWD_H2_MINPOS[0]
 
 
+# Training DATA GRADIENTS of the convs on the f16x2-split kernel (i2r_conv2d_dgrad_h2: the forward kernel on transposed,
+# tap-flipped weights, dy scaled by a per-tensor power of two so that it splits at full precision).  "auto": convs with
+# at least _TRAIN_BWD_H2_MINPOS positions -- each such layer pays ~3 small launches (weight split, abs-max, scale) and
+# the kernel splits dy itself, so it wins only where the exact fp32-MFMA kernel is clearly matrix-pipe bound (measured,
+# graph-mode step: threshold 8192 loses 8 % on B1/C/A, 32768 gains 2.3 % on D and leaves the others alone); "0": never.
+# Weight gradients stay exact fp32.
+_TRAIN_BWD_H2 = [os.environ.get("I2R_TRAIN_BWD_H2", "auto")]
+_TRAIN_BWD_H2_MINPOS = [int(os.environ.get("I2R_TRAIN_BWD_H2_MINPOS", 32768))]
+
+
+def train_bwd_h2(npos) -> bool:
+    return h2_math() and _TRAIN_BWD_H2[0] != "0" and _TRAIN_FWD_H2[0] != "0" and npos >= _TRAIN_BWD_H2_MINPOS[0]
+
+
+def set_train_bwd_h2(mode, minpos=None) -> None:
+    mode = {True: "auto", False: "0"}.get(mode, mode)
+    if mode not in ("auto", "0"):
+        raise ValueError(mode)
+    _TRAIN_BWD_H2[0] = mode
+    if minpos is not None:
+        _TRAIN_BWD_H2_MINPOS[0] = int(minpos)
+
+
 def train_fwd_h2_enabled() -> bool:
     """May ANY training conv forward run on the f16x2 kernel (whose operands must stay below fp16's 65504)?"""
     return h2_math() and _TRAIN_FWD_H2[0] != "0"
@@ -303,6 +326,55 @@ def conv2d_pack_h2(w):
     wp = torch.empty((n,), dtype=torch.uint8, device=w.device)
     _lib.call("i2r_conv2d_pack_weight_h2", _p(w), _p(wp), Cout, Cin, k, _stream())
     return wp
+
+
+def conv2d_pack_h2_dgrad(w):
+    """OIHW fp32 weights -> split-f16 packed layout of the data-gradient problem (transposed, taps flipped)."""
+    _chk(w, "w")
+    Cout, Cin, k, k2 = w.shape
+    if k != k2 or k not in (1, 3):
+        raise ValueError(f"conv2d: kernel {k}x{k2} unsupported")
+    n = _lib.query("i2r_conv2d_packed_h2_bytes", Cin, Cout, k)
+    wp = torch.empty((n,), dtype=torch.uint8, device=w.device)
+    _lib.call("i2r_conv2d_pack_weight_h2_dgrad", _p(w), _p(wp), Cout, Cin, k, _stream())
+    return wp
+
+
+_SCALE_SCRATCH = {}
+
+
+def _scale_scratch(device):
+    """One zeroed uint32 per device for i2r_absmax_pow2_scale_f32 (the kernel leaves it zero).  Made outside any
+    stream capture: the first data-gradient call of a process is always an eager one (graph warm-up)."""
+    t = _SCALE_SCRATCH.get(device)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.I2RError("conv2d_dgrad_h2: first use inside a stream capture; run one eager step first")
+        t = _SCALE_SCRATCH[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def absmax_pow2_scale(x):
+    """Device float[2] {s, 1/s}: s the power of two that puts max|x| into [2^13, 2^14)."""
+    _chk(x, "x")
+    scale = torch.empty((2,), dtype=torch.float32, device=x.device)
+    _lib.call("i2r_absmax_pow2_scale_f32", _p(x), x.numel(), _p(_scale_scratch(x.device)), _p(scale), _stream())
+    return scale
+
+
+def conv2d_dgrad_h2(dy, w_shape, wpd):
+    """dx = conv2d(dy, flip(w)^T) on the f16x2-split kernel at fp32-grade accuracy; ``wpd`` from conv2d_pack_h2_dgrad."""
+    _chk(dy, "dy")
+    Cout, Cin, k, _ = w_shape
+    B, Cout2, H, W = dy.shape
+    if Cout2 != Cout:
+        raise ValueError("conv2d_dgrad_h2: channel mismatch")
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    scale = absmax_pow2_scale(dy)
+    nsk = _lib.query("i2r_conv2d_splitk_h2_floats", B, Cout, H, W, Cin, k)
+    ws = torch.empty((nsk,), dtype=torch.float32, device=dy.device) if nsk > 0 else None
+    _lib.call("i2r_conv2d_dgrad_h2", _p(dy), _p(wpd), _p(dx), _p(scale), _p(ws), nsk, B, Cin, H, W, Cout, k, _stream())
+    return dx
 
 
 def conv2d_fwd_h2(x, w_shape, wp, bias=None, residual=None, x_split=False, out=None, qkv_out=False, up_in=False,
@@ -670,11 +742,12 @@ class Conv2dFn(torch.autograd.Function):
     """conv2d + bias + residual (networks.py:87-89 and the x.add_ of :178/:185)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, wp=None, wpd=None, wph=None):
+    def forward(ctx, x, w, bias, residual, wp=None, wpd=None, wph=None, wpd_h2=None):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.wpd = wpd  # weights already packed for the data gradient (DhariwalUNet.pack_all_weights), or None
+        ctx.wpd_h2 = wpd_h2  # split-f16 data-gradient weights: dx then runs on the f16x2 kernel (large layers)
         ctx.slots = (param_slot(w), param_slot(bias))
         if wph is not None:  # forward on the f16x2-split kernel (~1e-6); the gradients below use the exact kernels
             return conv2d_fwd_h2(x, tuple(w.shape), wph, bias, None if residual is None else _c(residual))
@@ -686,7 +759,8 @@ class Conv2dFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad(dy, w, ctx.wpd)
+            dx = conv2d_dgrad_h2(dy, tuple(w.shape), ctx.wpd_h2) if ctx.wpd_h2 is not None else \
+                conv2d_dgrad(dy, w, ctx.wpd)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             sw, sb = ctx.slots
             use = sw is not None and (sb is not None or not ctx.has_bias)
@@ -694,7 +768,7 @@ class Conv2dFn(torch.autograd.Function):
                                   db=sb.detach() if (use and ctx.has_bias) else None,
                                   accumulate=use and slots_zeroed())
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 class Down2Fn(torch.autograd.Function):

@@ -80,6 +80,19 @@ long i2r_conv2d_splitk_h2_floats(int B, int Cin, int H, int W, int Cout, int ksi
 int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                       float* splitk_ws, long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize,
                       int x_is_split, i2r_stream_t stream);
+/* Data gradient of the same convolution (autograd of conv2d w.r.t. x, as i2r_conv2d_dgrad_f32) on the f16x2-split
+ * kernel: weights packed once per weight version by the _dgrad pack routine (byte count:
+ * i2r_conv2d_packed_h2_bytes(Cin, Cout, ksize), the transposed problem), split-K workspace as for the forward of the
+ * transposed problem (i2r_conv2d_splitk_h2_floats(B, Cout, H, W, Cin, ksize)).  `scale`: device float[2] {s, 1/s}
+ * made by i2r_absmax_pow2_scale_f32 over dy -- gradients lie far below fp16's normal range; scaled by the power of
+ * two s they are split at full precision and the result is scaled back (both exact). */
+int i2r_conv2d_pack_weight_h2_dgrad(const float* w /* OIHW */, void* wp, int Cout, int Cin, int ksize,
+                                    i2r_stream_t stream);
+int i2r_conv2d_dgrad_h2(const float* dy, const void* wpd, float* dx, const float* scale, float* splitk_ws,
+                        long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize, i2r_stream_t stream);
+/* scale_out[0] = s = 2^(13 - floor(log2 max|x|)), scale_out[1] = 1/s (s = 1 when max|x| is 0 or not finite).
+ * scratch: one uint32, zero on entry, left zero.  (No counterpart in the reference: it serves the kernel above.) */
+int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* scale_out, i2r_stream_t stream);
 /* i2r_conv2d_fwd_h2 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that may
  * not call hipMalloc or hand over a workspace -- code under HIP graph capture, tight serving loops, harnesses that
  * forbid allocation.  Same arithmetic, same kernels, same split-K plan and therefore the same bits as

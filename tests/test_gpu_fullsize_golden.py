@@ -59,14 +59,18 @@ def conv_math(request):
     ops.new_pack_epoch()
 
 
-@pytest.fixture(params=["0", "1"], ids=["fwd_f32", "fwd_f16x2"])
+@pytest.fixture(params=["0", "1", "1+bwd"], ids=["fwd_f32", "fwd_f16x2", "fwd_and_dgrad_f16x2"])
 def train_fwd(request):
+    """Training conv forwards on the exact fp32 kernels / on the f16x2 kernels / forwards AND data gradients on the
+    f16x2 kernels (forced for every conv here; "auto" takes them above position thresholds).  Same 1e-4 bar."""
     from imageni2r_amd import ops
-    before = ops._TRAIN_FWD_H2[0]
-    ops.set_train_fwd_h2(request.param)
+    before = (ops._TRAIN_FWD_H2[0], ops._TRAIN_BWD_H2[0], ops._TRAIN_BWD_H2_MINPOS[0])
+    ops.set_train_fwd_h2(request.param[0])
+    ops.set_train_bwd_h2("auto" if request.param.endswith("bwd") else "0", minpos=0)
     ops.new_pack_epoch()
     yield request.param
-    ops.set_train_fwd_h2(before)
+    ops.set_train_fwd_h2(before[0])
+    ops.set_train_bwd_h2(before[1], minpos=before[2])
     ops.new_pack_epoch()
 
 
