@@ -448,6 +448,8 @@ static void gn_launch(const GnP& p, hipStream_t s) {
       hipLaunchKernelGGL(groupnorm_fwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
   } else if (n <= 64) {
     GN_GO(16, 1);
+  } else if (n <= 128) {
+    GN_GO(32, 1);  // 8 channels x 4x4 (256-wide levels at 4x4): 32 lanes carry data, not half of 64
   } else if (n <= 256) {
     GN_GO(64, 1);
   } else if (n <= 512) {
