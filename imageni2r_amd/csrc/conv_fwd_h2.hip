@@ -164,8 +164,21 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
 // consecutive positions of one channel: 16 b128 stores + 16 b128 residual loads + 16 bias loads per tile.
 // Needs W % 4 == 0 (a position quad inside one image row).  `scratch`: this wave's 32 x 36 floats.
 #define EPI_PITCH 36
+// The quad epilogue's 16 bias values of a lane (channel offsets 8 q + (lane >> 3) of the tile at m0).
+__device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, int m0, int lane, float (&bv)[16]) {
+  const int cr = lane >> 3, lim = p.Cout - m0 - cr;
+  const bool use_bias = full && p.bias != nullptr;
+  __amdgpu_buffer_rsrc_t rBias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
+  const unsigned boff = (unsigned)(m0 + cr) * 4u;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
+}
+
+// bias_pre: the lane's h2_quad_bias values when the caller already holds them (a position loop loads them once).
 __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
-                                                 long nw, int m0, int lane, float* scratch, int ablate, float omul) {
+                                                 long nw, int m0, int lane, float* scratch, int ablate, float omul,
+                                                 const float* bias_pre = nullptr) {
   const int l31 = lane & 31, h = lane >> 5, cr = lane >> 3, pq = (lane & 7) * 4;
   const long nq = nw + pq;
   const bool qvalid = nq < p.Npos;
@@ -175,7 +188,7 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
     pos = (unsigned)(nq - (long)pb * p.HW);
   }
   const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
-  const bool use_bias = full && p.bias != nullptr, use_res = full && p.res != nullptr;
+  const bool use_res = full && p.res != nullptr;
   const unsigned plane = (unsigned)p.HW * 4;
   const unsigned crow = pb * (unsigned)p.Cout + (unsigned)(m0 + cr);  // (sample, channel) plane index of this lane
   const unsigned voff = qvalid ? (crow * (unsigned)p.HW + pos) * 4u : OOR;
@@ -189,15 +202,16 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
   __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rR =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, use_res ? (int)res_bytes : 0, 0x00020000);
-  __amdgpu_buffer_rsrc_t rBias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
   const int lim = p.Cout - m0 - cr;  // channel offsets below lim exist for this lane
-  const unsigned boff = (unsigned)(m0 + cr) * 4u;
   const int cmod = (m0 + cr) % 3;
   // every load before the first store (see the aliasing note above)
   float bv[16], rv[16][4];
+  if (bias_pre) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
+    for (int q = 0; q < 16; ++q) bv[q] = bias_pre[q];
+  } else {
+    h2_quad_bias(p, full, m0, lane, bv);
+  }
   if (p.up_res) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {  // tile t = q / 4 covers channel offsets 32 t + 8 i + cr = 8 q + cr
@@ -505,6 +519,101 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
                 omul);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions with a SHORT contraction (Cin <= 128: the qkv / proj convs of the 128-channel levels) as a
+// weight-stationary, barrier-free position loop.  Measured on the tiled kernel above (128 -> 384 qkv conv, 512 samples
+// at 16x16: 94.7 us): a workgroup with its main loop AND its stores compiled out still costs 34 us of that -- 3072
+// workgroups of two K chunks each are all prologue / epilogue, and with two 256-VGPR workgroups per CU nothing
+// overlaps one's loads with the other's stores.  Here one 8-wave workgroup per CU stages the whole 128-row weight tile
+// (both chunks, hi + lo: 72 KB) in LDS ONCE, then every wave walks its own 32-position slices of the workgroup's
+// position tiles with no barrier at all: waves drift apart, so one wave's epilogue stores run beside another's
+// activation loads and MFMAs.  Same fragments, same MFMA order per output element, same epilogue as the tiled kernel
+// => the same bits.
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void conv1x1_h2_persist_kernel(ConvHParams p, int nworkers, int tile0,
+                                                                    int ntiles) {
+  constexpr int BM = 128, NW = 8, BN = 32 * NW, KC = 64, NKS = KC / 16;
+  constexpr int ROWL = KC * 2 + 16, RB = 2 * KC * 2, PPR = RB / 16, ABUF = 2 * BM * ROWL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  // same XCD-aware order as the tiled kernel: the Cout tiles that share a position range sit on one XCD's L2
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int mt = q % p.mtiles;
+  const int worker = (q / p.mtiles) * 8 + xcd;
+  if (worker >= nworkers) return;  // grid padding (whole workgroup, before the only barrier)
+  const int first = tile0 + worker;  // this launch walks position tiles [tile0, ntiles)
+  const int m0 = mt * BM;
+  const int nch = p.nCB;           // 1 or 2 chunks of 64 channels (checked on the host)
+
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  for (int idx = tid; idx < nch * BM * PPR; idx += 64 * NW) {
+    const int c = idx / (BM * PPR), r = idx - c * (BM * PPR);
+    const int row = r / PPR, piece = r - row * PPR, lo = piece >= PPR / 2;
+    const unsigned voff = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * RB + piece * 16) : OOR;
+    const uint4v v = bufload4(rA, voff, (unsigned)c * (unsigned)p.Cout * RB);
+    *reinterpret_cast<uint4v*>(smem + c * ABUF + (lo ? BM * ROWL : 0) + row * ROWL + (piece - lo * (PPR / 2)) * 16) = v;
+  }
+  __syncthreads();
+  float* scratch = reinterpret_cast<float*>(smem + nch * ABUF) + wave * (32 * EPI_PITCH);
+
+  float s_in = 1.0f, omul = WSCALE_INV;
+  if (!SPLIT && p.in_scale != nullptr) {
+    s_in = p.in_scale[0];
+    omul = WSCALE_INV * p.in_scale[1];
+  }
+  const unsigned chan_bytes = (unsigned)p.HW * 4;
+  float bv[16];  // loop-invariant: this lane's channels are the same in every position tile
+  h2_quad_bias(p, true, m0, lane, bv);
+  auto tile_voff = [&](int nt) -> unsigned {  // this lane's activation offset in position tile nt (OOR past the end)
+    const long nj = (long)nt * BN + wave * 32 + l31;
+    if (nt >= ntiles || nj >= p.Npos) return OOR;
+    const int pb = (int)(nj / p.HW), pos = (int)(nj - (long)pb * p.HW);
+    return (unsigned)((((long)pb * p.Cin + 8 * h) * p.HW + pos) * 4);
+  };
+  // rb[kq] = the 8 activations of k-step kq.  Software pipeline: as soon as a k-step's registers have been turned into
+  // fragments they are re-requested for the NEXT tile, so those loads fly under this tile's MFMAs and epilogue stores
+  // (the epilogue itself loads nothing: no residual on this path, bias hoisted).
+  float rb[2 * NKS][8];
+  auto request = [&](int kq, unsigned voff) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rb[kq][j] = bufload(rB, (kq < nch * NKS) ? voff : OOR, (unsigned)(kq * 16 + j) * chan_bytes);
+  };
+  {
+    const unsigned v0 = tile_voff(first);
+#pragma unroll
+    for (int kq = 0; kq < 2 * NKS; ++kq) request(kq, v0);
+  }
+  for (int nt = first; nt < ntiles; nt += nworkers) {
+    const unsigned vnext = tile_voff(nt + nworkers);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+    for (int kq = 0; kq < 2 * NKS; ++kq) {
+      half8 bh, bl;
+      if (SPLIT) unpack8(rb[kq], bh, bl);
+      else split8s(rb[kq], s_in, bh, bl);
+      request(kq, vnext);
+      if (kq < nch * NKS && !(p.ablate & 2)) {  // (wave-uniform)
+        const unsigned char* a_base = smem + (kq / NKS) * ABUF + (l31 * ROWL + 16 * h) + (kq % NKS) * 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const half8 ah = *reinterpret_cast<const half8*>(a_base + t * 32 * ROWL);
+          const half8 al = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    h2_epilogue_quad(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
+  }
+}
+
 // out = sum_z slab[z] + bias + residual
 __global__ void splitk_reduce_h2_kernel(const float* __restrict__ slabs, long slab_stride, int nsplit,
                                         const float* __restrict__ bias, const float* __restrict__ res,
@@ -767,6 +876,40 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.in_scale = in_scale;  // (null on every forward call: the un-split path then multiplies by exactly 1)
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);
+  // short-K 1x1: the weight-stationary position loop (conv1x1_h2_persist_kernel)
+  const char* pe = getenv("I2R_H2_PERSIST");  // (read per call: the A/B probe flips it inside one process)
+  const bool persist_on = !(pe && atoi(pe) == 0);
+  if (persist_on && ksize == 1 && !x2 && !residual && chunks <= 2 && nsplit == 1 && !up_in && (W & 3) == 0 &&
+      Npos >= 256L * 256) {
+    // Launched in spans of at most 1024 position tiles: the Cout-tile workers that share a position range run
+    // unsynchronised, and over a longer walk they drift apart until the shared activations have left the L2
+    // (measured at 8192 tiles: 0.85x of the tiled kernel; in spans of 1024: 1.3x).
+    const int all_tiles = i2r_cdiv(Npos, 256);
+    int cap = 256 / p.mtiles;                 // one 8-wave workgroup per CU (110 KB of LDS)
+    if (cap < 1) cap = 1;
+    const int lds = chunks * 2 * 128 * (64 * 2 + 16) + 8 * 32 * EPI_PITCH * 4;
+#define H2_PERSIST(SP_)                                                                                       \
+  do {                                                                                                        \
+    auto kern = conv1x1_h2_persist_kernel<SP_>;                                                               \
+    static bool attr = false;                                                                                 \
+    if (!attr) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                2 * 2 * 128 * (64 * 2 + 16) + 8 * 32 * EPI_PITCH * 4);                        \
+      attr = true;                                                                                            \
+    }                                                                                                         \
+    for (int tile0 = 0; tile0 < all_tiles; tile0 += 1024) {                                                   \
+      const int ntiles = tile0 + 1024 < all_tiles ? tile0 + 1024 : all_tiles;                                 \
+      const int rounds = i2r_cdiv(ntiles - tile0, cap);                                                       \
+      const int nworkers = i2r_cdiv(ntiles - tile0, rounds); /* each walks `rounds` (or rounds - 1) tiles */  \
+      dim3 pgrid((nworkers + 7) / 8 * 8 * p.mtiles);                                                          \
+      hipLaunchKernelGGL(kern, pgrid, dim3(512), lds, s, p, nworkers, tile0, ntiles);                         \
+    }                                                                                                         \
+  } while (0)
+    if (x_is_split) H2_PERSIST(true);
+    else H2_PERSIST(false);
+#undef H2_PERSIST
+    return i2r_check_launch("conv1x1_h2_persist");
+  }
   dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);
   const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);  // two weight stages (hi + lo rows each)
   // DPP tap reuse needs lanes = consecutive positions of one image row: W a power of two <= 32

@@ -28,6 +28,8 @@ ap.add_argument("--op", default="fwd")
 ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS probe)")
 ap.add_argument("--set", default="", help="named shape set: b1_1024")
 ap.add_argument("--split-in", action="store_true", help="h2: feed pre-split activations")
+ap.add_argument("--qkv-out", action="store_true", help="h2: store split pairs with q pre-scaled (the qkv conv's mode)")
+ap.add_argument("--res", action="store_true", help="h2: add a residual in the epilogue")
 a = ap.parse_args()
 shapes = a.shape or (SHAPES_B1_1024 if a.set == "b1_1024" else SHAPES_B1_256)
 dev = "cuda"
@@ -44,10 +46,8 @@ for sh in shapes:
         fn = lambda: ops.conv2d_fwd(x, w, b, None, wp)
     elif a.op == "h2":
         wph = ops.conv2d_pack_h2(w)
-        fn = lambda: ops.conv2d_fwd_h2(x, w.shape, wph, b, None, a.split_in)
-        ref = ops.conv2d_fwd(x, w, b, None)
-        err = (fn() - ref).abs().max().item() / ref.abs().max().item()
-        print(f"   h2 vs f32 max rel err {err:.2e}")
+        res = torch.randn(B, Cout, H, H, device=dev) if a.res else None
+        fn = lambda: ops.conv2d_fwd_h2(x, w.shape, wph, b, res, a.split_in, None, a.qkv_out)
     elif a.op == "dgrad":
         fn = lambda: ops.conv2d_dgrad(dy, w)
     else:
@@ -63,4 +63,6 @@ for sh in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     fl = 2.0 * B * H * H * Cout * Cin * k * k
-    print(f"{a.op} B{B} Cin{Cin} Cout{Cout} H{H} k{k}: {ms*1e3:8.1f} us  {fl/ms*1e-9:7.1f} TFLOP/s", flush=True)
+    nbytes = 4.0 * B * H * H * (Cin + Cout * (2 if (a.op == "h2" and a.res) else 1))
+    print(f"{a.op} B{B} Cin{Cin} Cout{Cout} H{H} k{k}: {ms*1e3:8.1f} us  {fl/ms*1e-9:7.1f} TFLOP/s  "
+          f"{nbytes/ms*1e-6:7.0f} GB/s", flush=True)
