@@ -6,7 +6,7 @@ Drop-in classes (same names / signatures / state-dict keys as the reference's mo
 MI355X-side additions (no counterpart in the reference): FusedAdamW (clip + AdamW + EMA in one multi-tensor kernel
 step), GraphedTrainStep (the whole train step as one replayed HIP graph), set_deterministic (reproducible gradient
 summation order), tst_boundary.TrainIteration (the reference's loop body on the TST / diffusion step boundary) and
-metrics (the evaluation stage's scores, kept on the device).
+metrics / context_fid (the evaluation stage's scores, kept on the device).
 All arithmetic runs in libi2r_hip.so (imageni2r_amd/csrc, C ABI in include/i2r_hip.h); importing this package does not
 need a GPU, calling an op does (there is no CPU fallback).
 """

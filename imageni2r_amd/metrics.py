@@ -12,7 +12,8 @@ and copied host->device twice per iteration (2 x 2000 copies), the per-iteration
 Same algorithms, same hyper-parameters, same random-number consumption order (numpy's global generator for the
 splits / mini-batches, torch's for the network initialisation): with the same seeds on the same device the
 discriminative score is bit-identical to the reference's (tests/test_metrics_cpu.py checks that in the build
-container against the imported reference).  Context-FID (metrics/context_fid.py: a TS2Vec encoder fit) is not built.
+container against the imported reference).  Context-FID (metrics/context_fid.py: a TS2Vec encoder fit) lives in
+imageni2r_amd/context_fid.py and is dispatched from here.
 """
 from __future__ import annotations
 
@@ -154,14 +155,16 @@ def calculate_pearson_correlation(real_sig, gen_sig, device="cpu"):
 
 
 def evaluate_model_irregular(real_sig, gen_sig, args, calc_other_metrics=False, metric_iteration=1):
-    """Dispatcher with the reference's keys (metrics/__init__.py:8-52).  ``calc_other_metrics``: predictive and
-    correlation scores (context-FID is not built: its keys are present with value None)."""
+    """Dispatcher with the reference's keys (metrics/__init__.py:8-52).  ``calc_other_metrics``: predictive score,
+    context-FID and correlation score, evaluated in the reference's order (they share the random generators)."""
     if calc_other_metrics:
+        from .context_fid import calculate_fid
         pred = [predictive_score_metrics(real_sig, gen_sig, device=args.device) for _ in range(metric_iteration)]
         pred_mean, pred_std = np.round(np.mean(pred), 4), np.round(np.std(pred), 4)
+        fid_mean, fid_std, fid_ci = calculate_fid(real_sig, gen_sig, device=args.device)
         corr_mean, corr_std, corr_ci = calculate_pearson_correlation(real_sig, gen_sig, device=args.device)
-        return {'pred_score_mean': pred_mean, 'pred_score_std': pred_std, 'fid_score_mean': None,
-                'fid_score_std': None, 'fid_score_conf_interval': None, 'correlation_score_mean': corr_mean,
+        return {'pred_score_mean': pred_mean, 'pred_score_std': pred_std, 'fid_score_mean': fid_mean,
+                'fid_score_std': fid_std, 'fid_score_conf_interval': fid_ci, 'correlation_score_mean': corr_mean,
                 'correlation_score_std': corr_std, 'correlation_score_conf_interval': corr_ci}
     disc = [discriminative_score_metrics(real_sig, gen_sig, args) for _ in range(metric_iteration)]
     return {'disc_mean': np.round(np.mean(disc), 4), 'disc_std': np.round(np.std(disc), 4)}

@@ -400,8 +400,46 @@ def g8_metrics():
         json.dump(out, f, indent=1)
 
 
+def g9_context_fid():
+    """Context-FID from the reference's own classes (metrics/context_fid.py).  `Context_FID` hard-codes device=0, so its
+    five statements are issued here with device='cpu' -- same constructor arguments, same call order -- plus one
+    ragged case (NaN-padded heads / tails, which takes the centring branch of fit)."""
+    from metrics.context_fid import TS2Vec, calculate_fid_score  # (reference)
+    real, gen = metric_inputs()
+    out = {"real_sha": hashlib.sha256(real.tobytes()).hexdigest()[:16],
+           "gen_sha": hashlib.sha256(gen.tobytes()).hexdigest()[:16], "cases": []}
+
+    def one(ori, fake, seed, tag):
+        np.random.seed(seed); torch.manual_seed(seed)
+        model = TS2Vec(input_dims=ori.shape[-1], device="cpu", batch_size=8, lr=0.001, output_dims=320,
+                       max_train_length=3000)
+        losses = model.fit(ori.copy(), verbose=False)
+        r1 = model.encode(ori.copy(), encoding_window="full_series")
+        r2 = model.encode(fake.copy(), encoding_window="full_series")
+        idx = np.random.permutation(ori.shape[0])
+        fid = float(calculate_fid_score(r1[idx], r2[idx]))
+        case = {"tag": tag, "seed": seed, "fid": fid, "epoch_losses": [float(v) for v in losses],
+                "n_iters": int(model.n_iters), "repr_real_sum": float(r1.astype(np.float64).sum()),
+                "repr_gen_sum": float(r2.astype(np.float64).sum()),
+                "repr_real_head": [float(v) for v in r1[0, :8]], "repr_gen_head": [float(v) for v in r2[-1, :8]]}
+        out["cases"].append(case)
+        print("g9", tag, seed, fid, losses[-1], flush=True)
+
+    one(real, gen, 0, "dense")
+    one(real, gen, 3, "dense")
+    ragged_r, ragged_g = real.copy(), gen.copy()
+    ragged_r[:, :3] = np.nan; ragged_r[::2, -2:] = np.nan   # a common all-NaN head, a tail on every other series
+    ragged_g[1::3, 5] = np.nan
+    one(ragged_r, ragged_g, 1, "ragged")
+    with open(os.path.join(HERE, "g9_context_fid.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9_context_fid()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_metrics()
         sys.exit(0)
@@ -415,6 +453,7 @@ if __name__ == "__main__":
     g6_ema()
     g7_fullsize()
     g8_metrics()
+    g9_context_fid()
     for f in sorted(os.listdir(HERE)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(HERE, f)))
