@@ -67,7 +67,10 @@ def chan_rel_err(a, b):
 
 
 # ---------------------------------------------------------------- full-size golden cases (tests/golden/g7_fullsize.npz)
-FULLSIZE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768")
+FULLSIZE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24", "H_energy768", "I_weather96_32")
+# the CPU oracle's own forward + backward + sampling is run at these (the rest would take the CPU suite past minutes;
+# their goldens are checked against the HIP path on the GPU, and their init order / inputs on the CPU)
+FULLSIZE_ORACLE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24")
 
 
 def fullsize_inputs(name):

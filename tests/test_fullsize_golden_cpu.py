@@ -1,5 +1,6 @@
 """CPU checks against the FULL-SIZE reference goldens (tests/golden/g7_fullsize.npz + g7_init.json, made by
-tests/golden/make_golden.py from the imported reference at BASELINE shapes A, B1, C, D):
+tests/golden/make_golden.py from the imported reference at BASELINE shapes A, B1, C, D and at the reference's other
+architecture families F (64-channel mujoco), H (multipliers 1-2-4-8, energy-768), I (weather-96 on 32x32)):
 
 * our constructors draw all 550 tensors of every shape bit-identically to the reference (init order pinned at full
   size, so the fixtures need not store weights);
@@ -16,7 +17,7 @@ import pytest
 import torch
 
 from oracle import i2r_oracle as O
-from tests.helpers import (FULLSIZE, GOLDEN, as_f32, fullsize_inputs, load_golden, probe_vec, rel_err, rms_rel_err,
+from tests.helpers import (FULLSIZE, FULLSIZE_ORACLE, GOLDEN, as_f32, fullsize_inputs, load_golden, probe_vec, rel_err, rms_rel_err,
                            tensor_sha)
 
 INIT = json.load(open(os.path.join(GOLDEN, "g7_init.json")))
@@ -46,7 +47,7 @@ def test_fullsize_init_order_and_inputs(name):
         assert tensor_sha(v) == ref["inputs"][k], k
 
 
-@pytest.mark.parametrize("name", FULLSIZE)
+@pytest.mark.parametrize("name", FULLSIZE_ORACLE)
 def test_oracle_matches_reference_at_full_size(name):
     g = load_golden("g7_fullsize.npz")
     m, sd, args, S, d = build_state(name)
@@ -84,7 +85,7 @@ def test_oracle_matches_reference_at_full_size(name):
         assert rel_err(sdg[names[i]].grad.numpy().ravel(), small[off:off + n]) < 1e-4, names[i]
     # the sampled series: the oracle's own Heun loop at shapes whose 35 evaluations take seconds on the CPU;
     # img_to_ts bits from the reference's sample at every shape
-    if name in ("A_sine24", "B1_weather96"):
+    if name in ("A_sine24", "B1_weather96", "F_mujoco24"):
         with torch.no_grad():
             out = O.heun_sample(lambda xx, s: O.edm_precond(sdg, spec, xx, s), d["xT"])
         assert out.dtype == torch.float64
