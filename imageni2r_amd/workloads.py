@@ -22,13 +22,13 @@ WORKLOADS = {
     # The reference's remaining architecture families (not BASELINE shapes; reference-pinned parity cases):
     # F: configs/seq_len_24/mujoco.yaml -- the 64-channel net
     "F_mujoco24": dict(seq_len=24, delay=3, embedding=8, img_resolution=8, input_channels=14, unet_channels=64,
-                       ch_mult=[1, 2, 2, 2], attn_resolution=[8, 4, 2], batch_size=128, fwd_gflop=None),
+                       ch_mult=[1, 2, 2, 2], attn_resolution=[8, 4, 2], batch_size=128, fwd_gflop=0.311),
     # H: configs/seq_len_768/energy.yaml -- channel multipliers 1, 2, 4, 8 (1024 channels at 4x4)
     "H_energy768": dict(seq_len=768, delay=24, embedding=32, img_resolution=32, input_channels=28,
-                        ch_mult=[1, 2, 4, 8], attn_resolution=[32, 16, 8, 4, 2], batch_size=16, fwd_gflop=None),
+                        ch_mult=[1, 2, 4, 8], attn_resolution=[32, 16, 8, 4, 2], batch_size=16, fwd_gflop=40.17),
     # I: configs/seq_len_96/weather.yaml -- 96 steps on a 32x32 image (4 used columns), multipliers 1, 2, 2, 4
     "I_weather96_32": dict(seq_len=96, delay=24, embedding=32, img_resolution=32, input_channels=21,
-                           ch_mult=[1, 2, 2, 4], attn_resolution=[32, 16, 8, 4, 2], batch_size=32, fwd_gflop=None),
+                           ch_mult=[1, 2, 2, 4], attn_resolution=[32, 16, 8, 4, 2], batch_size=32, fwd_gflop=25.33),
 }
 
 
