@@ -29,6 +29,62 @@ def _as_device_tensor(data, device):
     return torch.as_tensor(np.asarray(data), dtype=torch.float32).to(device)
 
 
+def _graph_loop_enabled(x):
+    import os
+    return x.is_cuda and os.environ.get("I2R_METRICS_GRAPH", "1") != "0"
+
+
+def _train_graphed(model, loss_of, set_sizes, iterations, batch_size, device):
+    """The 2000-step mini-batch loop of a scoring network as ONE captured HIP graph replayed per iteration: the loop
+    is launch-latency bound (a GRU with a handful of hidden units), so capture is what a GPU can do for it.  Same
+    algorithm and the same numpy draws in the same order -- every iteration's two index permutations are drawn up
+    front and copied to the device once; Adam runs in torch's `capturable` form (its step counter on the device).
+    The three eager warm-up steps torch asks for before a capture are undone (weights restored, moments and step
+    counter zeroed in place).  Returns False -- with the model untouched -- when the step cannot be captured."""
+    params = [p for p in model.parameters()]
+    saved = [p.detach().clone() for p in params]
+    sizes = [min(batch_size, n) for n in set_sizes]
+    idx = [torch.zeros(k, dtype=torch.long, device=device) for k in sizes]
+    optimizer = torch.optim.Adam(params, capturable=True)
+    graph = torch.cuda.CUDAGraph()
+    try:
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                optimizer.zero_grad(set_to_none=True)
+                loss_of(*idx).backward()
+                optimizer.step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss_of(*idx).backward()
+            optimizer.step()
+    except Exception as e:  # e.g. a library call that cannot be captured: train eagerly instead
+        import warnings
+        warnings.warn(f"metrics: graph capture of the training step failed ({type(e).__name__}: {e}); eager loop")
+        with torch.no_grad():
+            for p, s0 in zip(params, saved):
+                p.copy_(s0)
+        return False
+    with torch.no_grad():
+        for p, s0 in zip(params, saved):
+            p.copy_(s0)
+        for st in optimizer.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"].zero_()
+    draws = np.stack([np.concatenate([np.random.permutation(n)[:k] for n, k in zip(set_sizes, sizes)])
+                      for _ in range(iterations)]) if iterations else np.zeros((0, sum(sizes)), dtype=np.int64)
+    all_idx = torch.as_tensor(draws, dtype=torch.long).to(device)
+    for i in range(iterations):
+        off = 0
+        for buf, k in zip(idx, sizes):
+            buf.copy_(all_idx[i, off:off + k])
+            off += k
+        graph.replay()
+    torch.cuda.current_stream(device).synchronize()  # the graph's buffers die with this frame
+    return True
+
+
 class Discriminator(nn.Module):
     """1-layer GRU over (B, L, C) + Linear on the last hidden state (discriminative_torch.py:67-81)."""
 
@@ -66,16 +122,22 @@ def discriminative_score_metrics(ori_data, generated_data, args, iterations=2000
     test_x, test_x_hat = ori[torch.as_tensor(te_o, device=device)], gen[torch.as_tensor(te_g, device=device)]
 
     model.train()
-    for _ in range(iterations):
-        ia = torch.as_tensor(np.random.permutation(len(train_x))[:batch_size], device=device)
-        ib = torch.as_tensor(np.random.permutation(len(train_x_hat))[:batch_size], device=device)
+
+    def d_loss_of(ia, ib):
         y_logit_real, _ = model(train_x[ia])
         y_logit_fake, _ = model(train_x_hat[ib])
-        d_loss = (F.binary_cross_entropy_with_logits(y_logit_real, torch.ones_like(y_logit_real)).mean()
-                  + F.binary_cross_entropy_with_logits(y_logit_fake, torch.zeros_like(y_logit_fake)).mean())
-        optimizer.zero_grad()
-        d_loss.backward()
-        optimizer.step()
+        return (F.binary_cross_entropy_with_logits(y_logit_real, torch.ones_like(y_logit_real)).mean()
+                + F.binary_cross_entropy_with_logits(y_logit_fake, torch.zeros_like(y_logit_fake)).mean())
+
+    if not (_graph_loop_enabled(train_x) and
+            _train_graphed(model, d_loss_of, (len(train_x), len(train_x_hat)), iterations, batch_size, train_x.device)):
+        for _ in range(iterations):
+            ia = torch.as_tensor(np.random.permutation(len(train_x))[:batch_size], device=device)
+            ib = torch.as_tensor(np.random.permutation(len(train_x_hat))[:batch_size], device=device)
+            d_loss = d_loss_of(ia, ib)
+            optimizer.zero_grad()
+            d_loss.backward()
+            optimizer.step()
 
     model.eval()
     with torch.no_grad():

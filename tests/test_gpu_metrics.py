@@ -42,3 +42,25 @@ def test_scores_on_device_tensors():
     np.random.seed(0); torch.manual_seed(0)
     disc = float(M.discriminative_score_metrics(real_d, gen_d, args, iterations=300))
     assert 0.0 <= disc <= 0.5
+
+
+def test_discriminator_loop_as_a_replayed_graph_equals_the_eager_loop(monkeypatch):
+    """On the GPU the discriminator's mini-batch loop runs as one captured HIP graph per iteration (metrics._train_graphed):
+    same draws, same algorithm (Adam in its capturable form) -- the score of a short run equals the eager loop's."""
+    from imageni2r_amd import metrics as M
+    real, gen = metric_inputs()
+    real_d, gen_d = torch.from_numpy(real).cuda(), torch.from_numpy(gen).cuda()
+    args = SimpleNamespace(input_size=real.shape[2], device="cuda")
+    got = {}
+    calls = []
+    orig = M._train_graphed
+    monkeypatch.setattr(M, "_train_graphed", lambda *a, **k: calls.append(1) or orig(*a, **k))
+    for mode in ("0", "1"):
+        monkeypatch.setenv("I2R_METRICS_GRAPH", mode)
+        np.random.seed(3); torch.manual_seed(3)
+        got[mode] = float(M.discriminative_score_metrics(real_d, gen_d, args, iterations=150))
+        state = np.random.get_state()[1][:4].tolist()   # both loops leave numpy's generator in the same state
+        got[mode + "_rng"] = state
+    assert len(calls) == 1                               # (the graph path was taken exactly when enabled)
+    assert abs(got["0"] - got["1"]) <= 1.0 / 32 + 1e-9, got   # accuracy of 64 test series: at most one flips
+    assert got["0_rng"] == got["1_rng"]
