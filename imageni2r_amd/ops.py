@@ -16,7 +16,14 @@ from . import _lib
 _vp = ctypes.c_void_p
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current device's current HIP stream as a C pointer.  (torch.cuda.current_stream() builds a Stream object,
+    ~9 us a call: with ~460 launches per eager training step that alone was 4 ms of a 31 ms step.)"""
+    if _raw_stream is not None:
+        return _vp(_raw_stream(torch.cuda.current_device()))
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
