@@ -17,6 +17,9 @@ imageni2r_amd/context_fid.py and is dispatched from here.
 """
 from __future__ import annotations
 
+import os
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -30,7 +33,6 @@ def _as_device_tensor(data, device):
 
 
 def _graph_loop_enabled(x):
-    import os
     return x.is_cuda and os.environ.get("I2R_METRICS_GRAPH", "1") != "0"
 
 
@@ -61,7 +63,6 @@ def _train_graphed(model, loss_of, set_sizes, iterations, batch_size, device):
             loss_of(*idx).backward()
             optimizer.step()
     except Exception as e:  # e.g. a library call that cannot be captured: train eagerly instead
-        import warnings
         warnings.warn(f"metrics: graph capture of the training step failed ({type(e).__name__}: {e}); eager loop")
         with torch.no_grad():
             for p, s0 in zip(params, saved):
@@ -110,7 +111,6 @@ def discriminative_score_metrics(ori_data, generated_data, args, iterations=2000
     gen = _as_device_tensor(generated_data, device)
     hidden_dim = 8 if args.input_size == 1 else int(args.input_size / 2)
     model = Discriminator(args.input_size, hidden_dim).to(device)
-    optimizer = torch.optim.Adam(model.parameters())
 
     def split(n, train_rate=0.8):
         idx = np.random.permutation(n)
@@ -131,6 +131,7 @@ def discriminative_score_metrics(ori_data, generated_data, args, iterations=2000
 
     if not (_graph_loop_enabled(train_x) and
             _train_graphed(model, d_loss_of, (len(train_x), len(train_x_hat)), iterations, batch_size, train_x.device)):
+        optimizer = torch.optim.Adam(model.parameters())
         for _ in range(iterations):
             ia = torch.as_tensor(np.random.permutation(len(train_x))[:batch_size], device=device)
             ib = torch.as_tensor(np.random.permutation(len(train_x_hat))[:batch_size], device=device)
