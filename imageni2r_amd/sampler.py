@@ -63,9 +63,10 @@ class DiffusionProcess:
         sigma_max = min(self.sigma_max, self.net.sigma_max)
         return karras_schedule(self.num_steps, sigma_min, sigma_max, self.rho)
 
-    def _loop(self, latents, t_host, sig_dev):
-        """The Heun loop (:45-63) on device buffers; t_host: python floats, sig_dev: fp32 device copy of t_steps."""
-        n = self.num_steps
+    def _loop(self, latents, t_host, sig_dev, steps=None):
+        """The Heun loop (:45-63) on device buffers; t_host: python floats, sig_dev: fp32 device copy of t_steps.
+        `steps`: only the first so many steps (the warm-up before a capture)."""
+        n = self.num_steps if steps is None else min(steps, self.num_steps)
         x_cur = ops.heun_init(latents, t_host[0])
         x_next = torch.empty_like(x_cur)
         d_cur = torch.empty_like(x_cur)
@@ -89,11 +90,13 @@ class DiffusionProcess:
         if entry is None:
             sig_dev = t_steps.to(device=latents.device, dtype=torch.float32)
             static_in = latents.clone()
-            # one eager pass on a side stream warms allocator + library state before capture
+            # two eager Heun steps (three denoiser evaluations: both of a full step's, and a last step's) on a side
+            # stream bring up everything that is set up lazily -- packed weights, affine plans, kernel attributes --
+            # before the capture; the whole 18-step loop is not needed for that
             side = torch.cuda.Stream(device=latents.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._loop(static_in, t_host, sig_dev)
+                self._loop(static_in, t_host, sig_dev, steps=2)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
