@@ -101,7 +101,8 @@ __device__ __forceinline__ void unpack8(const float* v, half8& hi, half8& lo) {
 // residual) is issued BEFORE the first store: the compiler must assume the output may alias them, so a load placed
 // after a store waits for it -- interleaved, the 64 elements become 64 serial load -> wait -> store round trips
 // (measured: 25 us per workgroup, more than the whole main loop of a 1x1 conv).
-__device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
+template <int NTL>
+__device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (&acc)[NTL], float* outp, bool full,
                                             bool nvalid, unsigned pb, unsigned pos, int m0, int h, int ablate,
                                             float omul) {
   const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
@@ -127,9 +128,9 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
       __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
   const unsigned boff = (unsigned)(m0 + 4 * h) * 4u;
   const int cmod = (m0 + 4 * h) % 3;  // (head, d, {q,k,v}) interleave: channel % 3 == 0 is a q row
-  float bv[4][16], rv[4][16];
+  float bv[NTL][16], rv[NTL][16];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NTL; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
@@ -139,7 +140,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
     }
   auto store_all = [&](auto qkv) {  // one straight-line run of 64 stores per output form (no per-element branch)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cof = t * 32 + (r & 3) + 8 * (r >> 2);
@@ -165,18 +166,20 @@ __device__ __forceinline__ void h2_epilogue(const ConvHParams& p, const f32x16 (
 // Needs W % 4 == 0 (a position quad inside one image row).  `scratch`: this wave's 32 x 36 floats.
 #define EPI_PITCH 36
 // The quad epilogue's 16 bias values of a lane (channel offsets 8 q + (lane >> 3) of the tile at m0).
-__device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, int m0, int lane, float (&bv)[16]) {
+template <int NQ>
+__device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, int m0, int lane, float (&bv)[NQ]) {
   const int cr = lane >> 3, lim = p.Cout - m0 - cr;
   const bool use_bias = full && p.bias != nullptr;
   __amdgpu_buffer_rsrc_t rBias =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
   const unsigned boff = (unsigned)(m0 + cr) * 4u;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
+  for (int q = 0; q < NQ; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
 }
 
 // bias_pre: the lane's h2_quad_bias values when the caller already holds them (a position loop loads them once).
-__device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[4], float* outp, bool full,
+template <int NTL>
+__device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[NTL], float* outp, bool full,
                                                  long nw, int m0, int lane, float* scratch, int ablate, float omul,
                                                  const float* bias_pre = nullptr) {
   const int l31 = lane & 31, h = lane >> 5, cr = lane >> 3, pq = (lane & 7) * 4;
@@ -205,23 +208,24 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
   const int lim = p.Cout - m0 - cr;  // channel offsets below lim exist for this lane
   const int cmod = (m0 + cr) % 3;
   // every load before the first store (see the aliasing note above)
-  float bv[16], rv[16][4];
+  constexpr int NQ = 4 * NTL;
+  float bv[NQ], rv[NQ][4];
   if (bias_pre) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bv[q] = bias_pre[q];
+    for (int q = 0; q < NQ; ++q) bv[q] = bias_pre[q];
   } else {
-    h2_quad_bias(p, full, m0, lane, bv);
+    h2_quad_bias<NQ>(p, full, m0, lane, bv);
   }
   if (p.up_res) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {  // tile t = q / 4 covers channel offsets 32 t + 8 i + cr = 8 q + cr
+    for (int q = 0; q < NQ; ++q) {  // tile t = q / 4 covers channel offsets 32 t + 8 i + cr = 8 q + cr
       const float a = bufload(rR, 8 * q < lim ? rvoff : OOR, (unsigned)(8 * q) * rplane);
       const float b = bufload(rR, 8 * q < lim ? rvoff + 4u : OOR, (unsigned)(8 * q) * rplane);
       rv[q][0] = a; rv[q][1] = a; rv[q][2] = b; rv[q][3] = b;
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const uint4v t4 = bufload4(rR, 8 * q < lim ? rvoff : OOR, (unsigned)(8 * q) * rplane);
       // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
       const unsigned u0 = t4.x, u1 = t4.y, u2 = t4.z, u3 = t4.w;
@@ -230,7 +234,7 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
     }
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NTL; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_PITCH + l31] = acc[t][r];
 #pragma unroll
@@ -273,9 +277,11 @@ __device__ __forceinline__ float from_lane_above(float v) {
 //   row ends -- a third of the vector-memory instructions and L1/L2 bytes of the plain im2col gather.
 // TERMS = 3: the full split product.  TERMS = 1: a_hi*b_hi only -- plain f16 operands, fp32 accumulation (~5e-4 per
 // layer): the optional reduced-precision inference path (set_conv_math("f16")).
-template <int KS, bool SPLIT, int NW, bool DPP, int TERMS = 3>
+// BM: rows (output channels) of the workgroup's tile -- 128, or 64 / 32 for layers with that few output channels (the
+// 64-channel net's convs, every net's output conv): the MFMAs of the empty rows are not issued.
+template <int KS, bool SPLIT, int NW, bool DPP, int TERMS = 3, int BM = 128>
 __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) {
-  constexpr int BM = 128, BN = 32 * NW, NT = 64 * NW;
+  constexpr int BN = 32 * NW, NT = 64 * NW, NTL = BM / 32;
   constexpr int KC = (KS == 3) ? 48 : 64;
   constexpr int NKS = KC / 16;             // MFMA k-steps per chunk
   constexpr int ROWL = KC * 2 + 16;        // LDS row bytes (odd multiple of 16 B -> conflict-free b128 rows)
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
   constexpr int NA = (BM * PPRL + NT - 1) / NT;       // weight pieces per thread per chunk
   constexpr int ABUF = 2 * BM * ROWL;      // bytes of one weight stage (hi rows, then lo rows)
   constexpr int NRAW = (KS == 3 && DPP) ? 1 : NKS;  // raw activation register sets per chunk
-  static_assert(TERMS == 1 || BM * PPR % NT == 0, "weight tile must divide over the threads");
+  static_assert(BM == 128 || BM == 64 || BM == 32, "Cout tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     int idx = tid + NT * j;
-    const bool used = idx < BM * PPRL;  // single-term, 8 waves: 1.5 pieces per thread -- the spare half-slot loads
+    const bool used = idx < BM * PPRL;  // (single-term 8 waves, short tiles): a spare slot loads
     int row = idx / PPRL, piece = idx % PPRL;  // nothing (out of range) and parks its zeros in a row's padding
     voffA[j] = (used && m0 + row < p.Cout) ? (unsigned)((m0 + row) * RB + piece * 16) : OOR;
     int lo = piece >= PPR / 2;
@@ -360,9 +366,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
     voffB2 = (nvalid && p.x2) ? (unsigned)(off2 * 4) : OOR;
   }
 
-  f32x16 acc[4];
+  f32x16 acc[NTL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NTL; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
@@ -460,10 +466,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
     for (int c = c_begin; c < c_end; ++c) {
       const int buf = (c - c_begin) & 1;
       const unsigned char* a_base = smem + buf * ABUF + (l31 * ROWL + 16 * h);
-      half8 af[2][8];
+      half8 af[2][2 * NTL];
       auto load_frags = [&](int slot, int ks) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NTL; ++t) {
           af[slot][2 * t] = *reinterpret_cast<const half8*>(a_base + t * 32 * ROWL + ks * 32);
           if (TERMS == 3)
             af[slot][2 * t + 1] = *reinterpret_cast<const half8*>(a_base + BM * ROWL + t * 32 * ROWL + ks * 32);
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
       };
       auto mfma12 = [&](int ks) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NTL; ++t) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bh[ks], acc[t], 0, 0, 0);
           if (TERMS == 3) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][2 * t], bl[ks], acc[t], 0, 0, 0);
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
       mfma12(NKS - 1);
       build_frags(nh, nl);
 #pragma unroll
-      for (int i = 0; i < 4 * TERMS; ++i) {
+      for (int i = 0; i < NTL * TERMS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 6 : 12, 0);  // VALU of the fragment build
+        __builtin_amdgcn_sched_group_barrier(0x002, (TERMS == 3 ? 6 : 12) * 4 / NTL, 0);  // VALU of the fragment build
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -512,10 +518,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
   const bool direct = p.nsplit == 1;
   float* outp = p.out + (direct ? 0 : (long)blockIdx.z * p.slab_stride);
   if ((p.W & 3) == 0 && !(p.ablate & 8))  // quad form: its LDS patch reuses the (now idle) weight stages
-    h2_epilogue_quad(p, acc, outp, direct, n0 + wave * 32, m0, lane,
+    h2_epilogue_quad<NTL>(p, acc, outp, direct, n0 + wave * 32, m0, lane,
                      reinterpret_cast<float*>(smem) + wave * (32 * EPI_PITCH), p.ablate, omul);
   else
-    h2_epilogue(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate,
+    h2_epilogue<NTL>(p, acc, outp, direct, nvalid, (unsigned)pb, nvalid ? (unsigned)(nj % p.HW) : 0u, m0, h, p.ablate,
                 omul);
 }
 
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_persist_kernel(ConvHParams 
   }
   const unsigned chan_bytes = (unsigned)p.HW * 4;
   float bv[16];  // loop-invariant: this lane's channels are the same in every position tile
-  h2_quad_bias(p, true, m0, lane, bv);
+  h2_quad_bias<16>(p, true, m0, lane, bv);
   auto tile_voff = [&](int nt) -> unsigned {  // this lane's activation offset in position tile nt (OOR past the end)
     const long nj = (long)nt * BN + wave * 32 + l31;
     if (nt >= ntiles || nj >= p.Npos) return OOR;
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_persist_kernel(ConvHParams 
         }
       }
     }
-    h2_epilogue_quad(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
+    h2_epilogue_quad<4>(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
   }
 }
 
@@ -910,35 +916,47 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
 #undef H2_PERSIST
     return i2r_check_launch("conv1x1_h2_persist");
   }
+  // 3x3 convs with few output channels run on a shorter Cout tile (the MFMAs of the empty rows are not issued)
+  const int bm = (ksize == 3 && !one_term && !getenv("I2R_H2_BM128")) ? (Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128) : 128;
+  p.mtiles = i2r_cdiv(Cout, bm);
   dim3 grid((i2r_cdiv(Npos, bn) + 7) / 8 * 8 * p.mtiles, 1, nsplit);
-  const int lds3 = 4 * 128 * (48 * 2 + 16), lds1 = 4 * 128 * (64 * 2 + 16);  // two weight stages (hi + lo rows each)
+  // two weight stages (hi + lo rows each); the quad epilogue's per-wave transpose patches reuse them
+  const int patches = (bn / 32) * 32 * EPI_PITCH * 4;
+  const int lds3 = max(4 * bm * (48 * 2 + 16), patches), lds1 = 4 * 128 * (64 * 2 + 16);
   // DPP tap reuse needs lanes = consecutive positions of one image row: W a power of two <= 32
   const bool dpp = ksize == 3 && W <= 32 && (W & (W - 1)) == 0 && !getenv("I2R_H2_NODPP");
-#define H2_LAUNCH(KS_, SP_, NW_, DP_, TM_)                                                                         \
+#define H2_LAUNCH(KS_, SP_, NW_, DP_, TM_, BM_)                                                                    \
   do {                                                                                                             \
-    auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_, TM_>;                                                          \
+    auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_, TM_, BM_>;                                                  \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                                KS_ == 3 ? lds3 : lds1);                                                           \
+                                KS_ == 3 ? 4 * 128 * (48 * 2 + 16) : lds1);                                        \
       attr = true;                                                                                                 \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), KS_ == 3 ? lds3 : lds1, s, p);                                  \
   } while (0)
-#define H2_PICK_NW(KS_, SP_, DP_, TM_)            \
-  do {                                            \
-    if (bn == 256) H2_LAUNCH(KS_, SP_, 8, DP_, TM_); \
-    else H2_LAUNCH(KS_, SP_, 4, DP_, TM_);        \
+#define H2_PICK_NW(KS_, SP_, DP_, TM_, BM_)            \
+  do {                                                 \
+    if (bn == 256) H2_LAUNCH(KS_, SP_, 8, DP_, TM_, BM_); \
+    else H2_LAUNCH(KS_, SP_, 4, DP_, TM_, BM_);        \
+  } while (0)
+#define H2_PICK_BM(SP_, DP_)                           \
+  do {                                                 \
+    if (bm == 32) H2_PICK_NW(3, SP_, DP_, 3, 32);      \
+    else if (bm == 64) H2_PICK_NW(3, SP_, DP_, 3, 64); \
+    else H2_PICK_NW(3, SP_, DP_, 3, 128);              \
   } while (0)
   if (ksize == 3) {
     if (x_is_split) {
-      if (dpp) { if (one_term) H2_PICK_NW(3, true, true, 1); else H2_PICK_NW(3, true, true, 3); }
-      else H2_PICK_NW(3, true, false, 3);
-    } else { if (dpp) H2_PICK_NW(3, false, true, 3); else H2_PICK_NW(3, false, false, 3); }
+      if (dpp) { if (one_term) H2_PICK_NW(3, true, true, 1, 128); else H2_PICK_BM(true, true); }
+      else H2_PICK_BM(true, false);
+    } else { if (dpp) H2_PICK_BM(false, true); else H2_PICK_BM(false, false); }
   } else {
-    if (x_is_split) H2_PICK_NW(1, true, false, 3);
-    else H2_PICK_NW(1, false, false, 3);
+    if (x_is_split) H2_PICK_NW(1, true, false, 3, 128);
+    else H2_PICK_NW(1, false, false, 3, 128);
   }
+#undef H2_PICK_BM
 #undef H2_PICK_NW
 #undef H2_LAUNCH
   if (nsplit > 1) {
