@@ -178,7 +178,9 @@ __device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, in
 }
 
 // bias_pre: the lane's h2_quad_bias values when the caller already holds them (a position loop loads them once).
-template <int NTL>
+// RES = false: the caller knows there is no residual -- not even the (null-descriptor) loads are issued: they would sit
+// behind the position loop's prefetches in the in-order vmcnt queue and make the epilogue wait for them.
+template <int NTL, bool RES = true>
 __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32x16 (&acc)[NTL], float* outp, bool full,
                                                  long nw, int m0, int lane, float* scratch, int ablate, float omul,
                                                  const float* bias_pre = nullptr) {
@@ -216,7 +218,12 @@ __device__ __forceinline__ void h2_epilogue_quad(const ConvHParams& p, const f32
   } else {
     h2_quad_bias<NQ>(p, full, m0, lane, bv);
   }
-  if (p.up_res) {
+  if (!RES) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rv[q][e] = 0.0f;  // (still added below: x + 0 keeps the bits of the loaded-zero form)
+  } else if (p.up_res) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {  // tile t = q / 4 covers channel offsets 32 t + 8 i + cr = 8 q + cr
       const float a = bufload(rR, 8 * q < lim ? rvoff : OOR, (unsigned)(8 * q) * rplane);
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_persist_kernel(ConvHParams 
         }
       }
     }
-    h2_epilogue_quad<4>(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
+    h2_epilogue_quad<4, false>(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
   }
 }
 
