@@ -435,8 +435,55 @@ def g9_context_fid():
         json.dump(out, f, indent=1)
 
 
+def delay_fuzz_cases(n=48, seed=2024):
+    """Random delay-embedding geometries (L, d, E, C) that the reference itself accepts (it raises when the columns
+    outnumber the embedding, img_transformations.py:86-98)."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        E = int(rng.choice([2, 3, 4, 8, 12, 16, 24, 32]))
+        d = int(rng.integers(1, E + 5))
+        L = int(rng.integers(E, E + d * (E - 1) + 1))
+        C = int(rng.choice([1, 2, 3, 7]))
+        try:
+            DelayEmbedder("cpu", L, d, E, 1, C).ts_to_img(torch.zeros(1, L, C))
+        except (IndexError, RuntimeError):
+            continue
+        cases.append((L, d, E, C))
+    return cases
+
+
+def g10_delay_fuzz():
+    """ts_to_img / mask / img_to_ts (fp32 and fp64 input) of the REFERENCE on 48 random geometries, incl. delay >
+    embedding (uncovered time steps), partial last columns, one-column images and L == E."""
+    out, meta = {}, []
+    for i, (L, d, E, C) in enumerate(delay_fuzz_cases()):
+        rng = np.random.default_rng(7000 + i)
+        B = 2
+        ts = rng.random((B, L, C), dtype=np.float32)
+        ts[0, rng.permutation(L)[: max(1, int(0.3 * L))], :] = np.nan
+        emb = DelayEmbedder("cpu", L, d, E, B, C)
+        img = emb.ts_to_img(torch.from_numpy(ts))
+        S = img.shape[-1]
+        t = f"c{i}"
+        out[t + "_ts"] = bits(ts)
+        out[t + "_img"] = bits(img.numpy())
+        out[t + "_shape"] = np.array(emb.img_shape, dtype=np.int64)
+        for dt, name in ((np.float32, "f32"), (np.float64, "f64")):
+            x = rng.standard_normal((B, C, S, S)).astype(dt)
+            out[t + f"_in_{name}"] = bits(x)
+            out[t + f"_out_{name}"] = bits(emb.img_to_ts(torch.from_numpy(x)).numpy())
+        meta.append(dict(tag=t, L=L, d=d, E=E, C=C, B=B, S=int(S)))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "g10_delay_fuzz.npz"), **out)
+    print("g10_delay_fuzz", len(meta), "cases", sorted({(m["L"], m["d"], m["E"]) for m in meta})[:6], "...")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10_delay_fuzz()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9_context_fid()
         sys.exit(0)
@@ -454,6 +501,7 @@ if __name__ == "__main__":
     g7_fullsize()
     g8_metrics()
     g9_context_fid()
+    g10_delay_fuzz()
     for f in sorted(os.listdir(HERE)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -104,3 +104,22 @@ def assert_close(a, b, tol, what=""):
     hide the error of the small ones in the second)."""
     e, r = rel_err(a, b), rms_rel_err(a, b)
     assert e < tol and r < tol, (what, "max/max %.3e rms %.3e (bar %.1e)" % (e, r, tol))
+
+
+def _O():
+    from oracle import i2r_oracle
+    return i2r_oracle
+
+
+def inverse_close(y, ref_bits, m):
+    """img_to_ts against the reference's bits.  Up to four cells per time step -- every reference config has <= 3 --
+    any summation order gives the same bits, and equality is required.  From five cells on ATen's CPU sum is not one
+    order: inside one call the first 4*(B*C//4) outputs are summed left to right and the rest as four interleaved
+    partial sums (scalar_outer_sum / row_sum in aten/src/ATen/native/cpu/SumKernel.cpp), and from B*C >= the host's
+    vector width the split moves with the CPU's SIMD ISA -- the reference's own last bit depends on the machine
+    there.  The build sums left to right; those outputs are held to 2 ulp."""
+    kmax = max(len(c) for c in _O().inverse_positions(m["L"], m["d"], m["E"]))
+    ref = as_f32(ref_bits)
+    if kmax <= 4:
+        return np.array_equal(y.view(np.uint32), ref_bits)
+    return bool(np.all(np.abs(y.astype(np.float64) - ref) <= 2.4e-7 * np.maximum(np.abs(ref), 0.25)))

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close, as_f32, as_f64, golden_meta, load_golden, probe_vec, rel_err, tiny_args
+from tests.helpers import (assert_close, as_f32, as_f64, golden_meta, inverse_close, load_golden, probe_vec, rel_err,
+                           tiny_args)
 from oracle import i2r_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +47,25 @@ def test_delay_embedding_bit_exact(ops):
             y = emb.img_to_ts(cu(conv(g[t + f"_inv_in_{name}"])))
             assert y.dtype == torch.float32
             assert np.array_equal(y.cpu().numpy().view(np.uint32), g[t + f"_inv_out_{name}"]), (t, name)
+
+
+def test_delay_embedding_random_geometries_bit_exact(ops):
+    """The HIP transforms on the reference's vectors for 48 random geometries (tests/golden/g10_delay_fuzz.npz)."""
+    from imageni2r_amd import DelayEmbedder
+    g = load_golden("g10_delay_fuzz.npz")
+    for m in golden_meta(g):
+        t = m["tag"]
+        emb = DelayEmbedder(DEV, m["L"], m["d"], m["E"], m["B"], m["C"])
+        img, mask = emb.ts_to_img_with_mask(cu(as_f32(g[t + "_ts"])))
+        ref = as_f32(g[t + "_img"])
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), g[t + "_img"]), m
+        assert np.array_equal(mask.cpu().numpy(), (~np.isnan(ref)).astype(np.float32)), m
+        assert tuple(emb.img_shape) == tuple(g[t + "_shape"]), m
+        for name, conv in (("f32", as_f32), ("f64", as_f64)):
+            y = emb.img_to_ts(cu(conv(g[t + f"_in_{name}"])))
+            assert y.dtype == torch.float32
+            assert inverse_close(y.cpu().numpy(), g[t + f"_out_{name}"], m), (m, name)   # bits up to 4 cells per step
+            assert np.array_equal(y.cpu().numpy(), O.img_to_ts(conv(g[t + f"_in_{name}"]), m["L"], m["d"], m["E"]))
 
 
 def test_delay_embedding_full_size_roundtrip_and_backward(ops):

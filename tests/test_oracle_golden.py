@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import as_f32, as_f64, golden_meta, load_golden, probe_vec, rel_err
+from tests.helpers import as_f32, as_f64, golden_meta, inverse_close, load_golden, probe_vec, rel_err
 from oracle import i2r_oracle as O
 
 TOL = 2e-5  # oracle and reference both run torch-CPU fp32 kernels; only op-order differences remain
@@ -37,6 +37,26 @@ def test_delay_embedding_bit_exact():
             x = conv(g[t + f"_inv_in_{name}"])
             y = O.img_to_ts(x, m["L"], m["d"], m["E"])
             assert np.array_equal(y.view(np.uint32), g[t + f"_inv_out_{name}"]), (t, name)
+
+
+def test_delay_embedding_random_geometries_bit_exact():
+    """48 random (seq_len, delay, embedding, channels) the reference accepts (g10: delay > embedding, partial last
+    column, one-column images, seq_len == embedding ...): image bits, cached shape, inverse for fp32 / fp64 input."""
+    g = load_golden("g10_delay_fuzz.npz")
+    metas = golden_meta(g)
+    assert len(metas) == 48
+    exact = 0
+    for m in metas:
+        t = m["tag"]
+        img = O.ts_to_img(as_f32(g[t + "_ts"]), m["d"], m["E"])
+        assert np.array_equal(img.view(np.uint32), g[t + "_img"]), m
+        cols, S = O.delay_geometry(m["L"], m["d"], m["E"])
+        assert tuple(g[t + "_shape"]) == (m["B"], m["C"], m["E"], cols) and S == m["S"], m
+        exact += max(len(c) for c in O.inverse_positions(m["L"], m["d"], m["E"])) <= 4
+        for name, conv in (("f32", as_f32), ("f64", as_f64)):
+            y = O.img_to_ts(conv(g[t + f"_in_{name}"]), m["L"], m["d"], m["E"])
+            assert inverse_close(y, g[t + f"_out_{name}"], m), (m, name)
+    assert exact == 42  # (geometries of the draw in the bit-exact class)
 
 
 def test_layers():
