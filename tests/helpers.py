@@ -67,10 +67,39 @@ def chan_rel_err(a, b):
 
 
 # ---------------------------------------------------------------- full-size golden cases (tests/golden/g7_fullsize.npz)
-FULLSIZE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24", "H_energy768", "I_weather96_32")
+# Small nets with topologies no reference config has (odd channel multipliers -> 3 and 6 attention heads, four levels
+# down to a 1x1 image with attention there, a single level without attention, nominal resolution != image side, widths
+# that shrink with depth): the plan builder, the tile / head / group dispatch and the sampler against the reference on
+# configurations it was never tuned for.
+EXTRA_NETS = {
+    "R0_c64_112": dict(seq_len=24, delay=3, embedding=8, img_resolution=8, input_channels=2, unet_channels=64,
+                       ch_mult=[1, 1, 2], attn_resolution=[4]),
+    "R1_c64_21": dict(seq_len=50, delay=7, embedding=16, img_resolution=16, input_channels=4, unet_channels=64,
+                      ch_mult=[2, 1], attn_resolution=[16, 8]),
+    "R2_c128_13": dict(seq_len=24, delay=3, embedding=8, img_resolution=8, input_channels=9, unet_channels=128,
+                       ch_mult=[1, 3], attn_resolution=[8]),
+    "R3_c64_1234": dict(seq_len=30, delay=4, embedding=8, img_resolution=8, input_channels=1, unet_channels=64,
+                        ch_mult=[1, 2, 3, 4], attn_resolution=[2, 1]),
+    "R4_c64_1": dict(seq_len=96, delay=6, embedding=16, img_resolution=16, input_channels=5, unet_channels=64,
+                     ch_mult=[1], attn_resolution=[]),
+    "R5_c64_12_nominal8": dict(seq_len=96, delay=6, embedding=16, img_resolution=8, input_channels=6, unet_channels=64,
+                               ch_mult=[1, 2], attn_resolution=[8]),
+}
+FULLSIZE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24", "H_energy768",
+            "I_weather96_32") + tuple(EXTRA_NETS)
 # the CPU oracle's own forward + backward + sampling is run at these (the rest would take the CPU suite past minutes;
 # their goldens are checked against the HIP path on the GPU, and their init order / inputs on the CPU)
-FULLSIZE_ORACLE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24")
+FULLSIZE_ORACLE = ("A_sine24", "B1_weather96", "C_electricity96", "D_etth1_768", "F_mujoco24") + tuple(EXTRA_NETS)
+
+
+def fullsize_args(name, device="cpu"):
+    from imageni2r_amd.workloads import WORKLOADS, workload_args
+    if name in WORKLOADS:
+        return workload_args(name, device=device)
+    d = dict(ema=True, ema_warmup=100, diffusion_steps=18, beta1=1e-5, betaT=1e-2, deterministic=False, batch_size=4)
+    d.update(EXTRA_NETS[name])
+    d["device"] = device
+    return SimpleNamespace(**d)
 
 
 def fullsize_inputs(name):
@@ -78,8 +107,8 @@ def fullsize_inputs(name):
     (which feeds them to the imported reference) and by the tests (torch's CPU generator is deterministic; the fixture
     stores a checksum of every tensor made here)."""
     import torch
-    from imageni2r_amd.workloads import image_side, workload_args
-    args = workload_args(name, device="cpu")
+    from imageni2r_amd.workloads import image_side
+    args = fullsize_args(name)
     S, C, L = image_side(args), args.input_channels, args.seq_len
     g = torch.Generator().manual_seed(7000 + FULLSIZE.index(name))
     d = {"x": torch.randn(2, C, S, S, generator=g), "sigma": torch.tensor([0.3, 7.0])}
