@@ -45,6 +45,17 @@ __device__ __forceinline__ float grp_sum(float v) {
     return (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
+// sum over all 256 threads of the workgroup (every thread must call it); `phase` alternates the LDS words so that a
+// wave already in the next call cannot overwrite what a slower wave is still reading
+__device__ __forceinline__ float wg256_sum(float v, int& phase) {
+  __shared__ float red[2][4];
+  v = seg_sum<64>(v);
+  if ((threadIdx.x & 63) == 0) red[phase][threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = (red[phase][0] + red[phase][1]) + (red[phase][2] + red[phase][3]);
+  phase ^= 1;
+  return r;
+}
 // sum over aligned runs of `w` lanes (w a power of two <= 64, wave-uniform)
 __device__ __forceinline__ float run_sum(float v, int w) {
 #pragma unroll
@@ -174,6 +185,17 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
   const int runw = q4 < LPG ? q4 : LPG;        // lanes of one slot that share a channel
   const int spc = q4 <= LPG ? 1 : q4 / LPG;    // slots per channel
 
+  // LPG = 256 (groups of 4097..16384 elements: the concatenated inputs of the 32x32 decoder blocks): the whole
+  // workgroup owns one group; a channel's lanes are a run inside one wave (HW <= 256) or the whole workgroup
+  int phase = 0;
+  auto chan_sum = [&](float v) -> float {
+    if constexpr (LPG <= 64) return run_sum(v, runw);
+    else return runw <= 64 ? run_sum(v, runw) : wg256_sum(v, phase);
+  };
+  auto group_sum = [&](float v) -> float {
+    if constexpr (LPG <= 64) return seg_sum<LPG>(v);
+    else return wg256_sum(v, phase);
+  };
   float4 xh[NV], dn[NV];  // xhat and d(loss)/d(normalised*gamma+beta) after modulation  (dn = du * (1+scale))
   float S1 = 0.0f, S2 = 0.0f;
   float a_du = 0.0f, a_dun = 0.0f, a_dn = 0.0f, a_dnx = 0.0f;
@@ -221,11 +243,11 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
     xh[k] = make_float4(xo[0], xo[1], xo[2], xo[3]);
     dn[k] = make_float4(dno[0] * gm, dno[1] * gm, dno[2] * gm, dno[3] * gm);  // now d/dxhat
     if ((k + 1) % spc == 0 || k == NV - 1) {  // channel complete in this lane's slots (spc, NV powers of two)
-      float r_dn = run_sum(a_dn, runw), r_dnx = run_sum(a_dnx, runw);
+      float r_dn = chan_sum(a_dn), r_dnx = chan_sum(a_dnx);
       S1 += gm * a_dn;
       S2 += gm * a_dnx;
       if (ssp) {
-        float r_du = run_sum(a_du, runw), r_dun = run_sum(a_dun, runw);
+        float r_du = chan_sum(a_du), r_dun = chan_sum(a_dun);
         if (in && (sl & (runw - 1)) == 0) {
           p.dss[(long)b * 2 * p.C + c] = r_dun;
           p.dss[(long)b * 2 * p.C + p.C + c] = r_du;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
     }
   }
   const float inv_n = 1.0f / (float)n;
-  const float m1 = seg_sum<LPG>(S1) * inv_n, m2 = seg_sum<LPG>(S2) * inv_n;
+  const float m1 = group_sum(S1) * inv_n, m2 = group_sum(S2) * inv_n;
   if (!valid) return;
   float4* dxp = reinterpret_cast<float4*>(p.y + base);
 #pragma unroll
@@ -430,7 +452,7 @@ template <bool BWD>
 static void gn_launch(const GnP& p, hipStream_t s) {
   const long groups = (long)p.B * p.G;
   const int n = (p.C / p.G) * p.HW;
-  const bool reg_ok = p.sh >= 2 && n <= (BWD ? 4096 : 16384) && (((uintptr_t)p.x) & 15) == 0 &&
+  const bool reg_ok = p.sh >= 2 && n <= 16384 && (((uintptr_t)p.x) & 15) == 0 &&
                       (((uintptr_t)p.y) & 15) == 0 && (!BWD || ((((uintptr_t)p.dy) | ((uintptr_t)p.add)) & 15) == 0);
 #define GN_GO(LPG, NV)                                                                                          \
   do {                                                                                                          \
@@ -458,12 +480,12 @@ static void gn_launch(const GnP& p, hipStream_t s) {
     GN_GO(64, 4);
   } else if (n <= 2048) {
     GN_GO(64, 8);
-  } else if (n <= 4096 || BWD) {
+  } else if (n <= 4096) {
     GN_GO(64, 16);
   } else if (n <= 8192) {
-    if constexpr (!BWD) hipLaunchKernelGGL((gn_fwd_reg_kernel<256, 8>), dim3(groups), dim3(256), 0, s, p);
+    GN_GO(256, 8);
   } else {
-    if constexpr (!BWD) hipLaunchKernelGGL((gn_fwd_reg_kernel<256, 16>), dim3(groups), dim3(256), 0, s, p);
+    GN_GO(256, 16);
   }
 #undef GN_GO
 }

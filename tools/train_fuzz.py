@@ -92,6 +92,18 @@ for it in range(N):
         check("gn_dbeta", db, br.grad, what)
         if mode == 2:
             check("gn_dss", dss, sr.grad, what)
+        # the training step's form: bypass gradient added to dx, dgamma / dbeta accumulated into zero-filled slots
+        add = torch.randn(B, C, H, H, device=dev, generator=g)
+        sg, sb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        prev = ops.slots_zeroed()
+        ops.set_slots_zeroed(True)
+        try:
+            dx2, dw2, db2, _ = ops.groupnorm_bwd(x, w, b, ss, mean, rstd, dy, G, mode >= 1, dgamma=sg, dbeta=sb, add=add)
+        finally:
+            ops.set_slots_zeroed(prev)
+        check("gn_dx_plus_add", dx2, xr.grad + add.double(), what)
+        check("gn_dgamma_slot", dw2, wr.grad, what)
+        check("gn_dbeta_slot", db2, br.grad, what)
     else:  # ---- attention
         heads = int(rng.choice([1, 2, 4, 8, 16]))
         H = int(rng.choice([1, 2, 4, 8, 16, 32]))
