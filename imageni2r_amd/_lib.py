@@ -55,6 +55,7 @@ SIGNATURES = {
     "i2r_reduce_rows2_f32": [P, P, P, I, I, I, P],
     "i2r_attention_fwd_f32": [P, P, P, I, I, I, P],
     "i2r_attention_fwd_h2": [P, P, I, I, I, I, P],
+    "i2r_attention_fwd_h2_lse": [P, P, P, I, I, I, P],
     "i2r_attention_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
     "i2r_pos_embedding_f32": [P, P, I, I, I, P],
     "i2r_linear_fwd_f32": [P, P, P, P, P, I, I, I, I, P],

@@ -203,7 +203,7 @@ __device__ __forceinline__ void a_unpack8(const float* v, ah8& hi, ah8& lo) {
 // PRE: qkv arrives pre-split (and q pre-scaled) from i2r_conv2d_fwd_h2's qkv output mode.
 template <int QW, bool PRE>
 __global__ __launch_bounds__(64 * QW, QW == 4 ? 3 : QW) void attn_fwd_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int heads, int T) {
+                                                              float* __restrict__ lse, int heads, int T) {
   constexpr int NT = 64 * QW, NIT = 256 / NT;                 // staging work items per thread
   constexpr int KBYTES = KT * AKROW, VBYTES = HD * AVROW;     // one of hi / lo
   constexpr int STAGE = 2 * KBYTES + 2 * VBYTES;
@@ -355,23 +355,39 @@ __global__ __launch_bounds__(64 * QW, QW == 4 ? 3 : QW) void attn_fwd_h2_kernel(
       int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       ob[(long)c * T + q0 + l31] = O[t][r] * inv_l;
     }
+  // training forward: the log-sum-exp the backward recomputes the probabilities from, in natural-log units like
+  // attn_fwd_kernel's (the scores here are in log2 units: q carries log2(e))
+  if (lse && h == 0) lse[(long)bh * T + q0 + l31] = (m_run + log2f(l_run)) * 0.6931471805599453f;
 }
 
 // f16x2-split inference forward; T must be a multiple of 32 and > 32 (smaller T: i2r_attention_fwd_f32's LDS kernel).
 // presplit: qkv was written by i2r_conv2d_fwd_h2 with flag bit 1 (split pairs, q pre-scaled).
-extern "C" int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, int presplit,
-                                    i2r_stream_t stream) {
+static int attention_fwd_h2_launch(const float* qkv, float* out, float* lse, int B, int heads, int T, int presplit,
+                                   i2r_stream_t stream) {
   I2R_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 32 && T % 32 == 0, "attention_fwd_h2: bad argument (T=%d)", T);
   I2R_REQUIRE((((uintptr_t)qkv) & 15) == 0, "attention_fwd_h2: qkv must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
 #define ATT_GO(QW_, PRE_)                                                                                          \
   hipLaunchKernelGGL((attn_fwd_h2_kernel<QW_, PRE_>), dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 0, s, qkv, out, \
-                     heads, T)
+                     lse, heads, T)
   if (T % 128 == 0) { if (presplit) ATT_GO(4, true); else ATT_GO(4, false); }
   else if (T % 64 == 0) { if (presplit) ATT_GO(2, true); else ATT_GO(2, false); }
   else { if (presplit) ATT_GO(1, true); else ATT_GO(1, false); }
 #undef ATT_GO
   return i2r_check_launch("attention_fwd_h2");
+}
+
+extern "C" int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, int presplit,
+                                    i2r_stream_t stream) {
+  return attention_fwd_h2_launch(qkv, out, nullptr, B, heads, T, presplit, stream);
+}
+
+// The same kernel as a TRAINING forward: plain fp32 qkv in, and the per-query log-sum-exp out (B * heads * T floats) for
+// i2r_attention_bwd_f32, which recomputes the probabilities from it.
+extern "C" int i2r_attention_fwd_h2_lse(const float* qkv, float* out, float* lse, int B, int heads, int T,
+                                        i2r_stream_t stream) {
+  I2R_REQUIRE(lse, "attention_fwd_h2_lse: null lse");
+  return attention_fwd_h2_launch(qkv, out, lse, B, heads, T, 0, stream);
 }
 
 extern "C" int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int heads, int T,

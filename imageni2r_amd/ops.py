@@ -587,6 +587,10 @@ def attention_fwd(qkv, heads, save_lse=False, presplit=False):
     if presplit:
         raise ValueError("attention_fwd: presplit qkv is only understood by the f16x2 inference kernel")
     lse = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device) if save_lse else None
+    if save_lse and T > 32 and T % 32 == 0 and train_fwd_h2_enabled():
+        # training forward on the f16x2 kernel (like the conv forwards; the backward stays on the exact fp32 kernels)
+        _lib.call("i2r_attention_fwd_h2_lse", _p(qkv), _p(out), _p(lse), B, heads, T, _stream())
+        return out, lse
     _lib.call("i2r_attention_fwd_f32", _p(qkv), _p(out), _p(lse), B, heads, T, _stream())
     return out, lse
 

@@ -170,6 +170,9 @@ int i2r_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int h
  * i2r_conv2d_fwd_h2); T a multiple of 32 and > 32; qkv 16-byte aligned.  presplit: qkv holds split pairs with q
  * pre-scaled (i2r_conv2d_fwd_h2 flag bit 1) -- the kernel then converts nothing. */
 int i2r_attention_fwd_h2(const float* qkv, float* out, int B, int heads, int T, int presplit, i2r_stream_t stream);
+/* The f16x2 kernel as the TRAINING forward of AttentionOp (networks.py:113-119): fp32 qkv in, and the per-query
+ * log-sum-exp out (B*heads*T floats, natural-log units) from which i2r_attention_bwd_f32 recomputes the probabilities. */
+int i2r_attention_fwd_h2_lse(const float* qkv, float* out, float* lse, int B, int heads, int T, i2r_stream_t stream);
 /* AttentionOp.backward (:121-126) + einsum backward: dqkv (B,3C,T); delta_ws: workspace of B*heads*T floats. */
 int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                           float* delta_ws, int B, int heads, int T, i2r_stream_t stream);

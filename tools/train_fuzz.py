@@ -118,7 +118,7 @@ for it in range(N):
         ref = torch.einsum("nqk,nck->ncq", wgt, v).reshape(B, C, H, H)
         ref.backward(da.double())
         a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
-        check("attn_fwd_f32", a, ref.detach(), what)
+        check("attn_fwd_train", a, ref.detach(), what)
         check("attn_bwd", ops.attention_bwd(qkv, a, lse, da, heads), qr.grad, what)
         if ops.attention_h2_ok(H * H):
             check("attn_fwd_h2", ops.attention_fwd(qkv, heads)[0], ref.detach(), what)
