@@ -404,10 +404,24 @@ extern "C" int i2r_pos_embedding_f32(const float* x, float* out, int B, int num_
 // factor 4 to spare, and everything down to 2^-27 of the peak stays representable.  max|x| = 0, inf or NaN: s = 1 (a
 // non-finite gradient then reaches the optimiser as such and its step is skipped).  `scratch`: one uint32 that is 0 on
 // entry and is left 0 (the bit pattern of a non-negative float orders like the float).
-__global__ void absmax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ scratch) {
+// 16-byte loads; one atomic per WORKGROUP, and only when it can still raise the maximum (a plain look first): with
+// one atomicMax per wave on the same word the 4096 waves of a 17 MB tensor queued at the L2 for 50 us -- ten times
+// what reading the tensor takes.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long n,
+                                                          unsigned* __restrict__ scratch) {
+  __shared__ unsigned red[4];
   unsigned m = 0;
-  GRID_STRIDE(i, n) {
-    unsigned b = __builtin_bit_cast(unsigned, x[i]) & 0x7FFFFFFFu;
+  const long n4 = (((uintptr_t)x) & 15) == 0 ? (n >> 2) : 0;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = t0; i < n4; i += stride) {
+    const uint4 v = x4[i];
+    const unsigned a = v.x & 0x7FFFFFFFu, b = v.y & 0x7FFFFFFFu, c = v.z & 0x7FFFFFFFu, d = v.w & 0x7FFFFFFFu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    m = q > m ? q : m;
+  }
+  for (long i = 4 * n4 + t0; i < n; i += stride) {
+    const unsigned b = __builtin_bit_cast(unsigned, x[i]) & 0x7FFFFFFFu;
     m = b > m ? b : m;
   }
 #pragma unroll
@@ -415,7 +429,13 @@ __global__ void absmax_bits_kernel(const float* __restrict__ x, long n, unsigned
     unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(scratch, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    m = a > b ? a : b;
+    if (m != 0 && m > *reinterpret_cast<volatile unsigned*>(scratch)) atomicMax(scratch, m);
+  }
 }
 __global__ void pow2_scale_kernel(unsigned* __restrict__ scratch, float* __restrict__ scale_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -435,7 +455,7 @@ __global__ void pow2_scale_kernel(unsigned* __restrict__ scratch, float* __restr
 extern "C" int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* scale_out,
                                          i2r_stream_t stream) {
   I2R_REQUIRE(x && scratch && scale_out && n > 0, "absmax_pow2_scale: bad argument");
-  int nb = ew_grid(n);
+  int nb = ew_grid((n + 3) / 4);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(absmax_bits_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
   hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, scale_out);
