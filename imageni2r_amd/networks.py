@@ -139,7 +139,8 @@ class Conv2d(torch.nn.Module):
                                          None if residual is None else ops._c(residual), x_split, out, qkv_out,
                                          False, up_res)
             if torch.is_grad_enabled() and ops.train_fwd_h2(x.shape[0] * x.shape[2] * x.shape[3]):
-                bwd_h2 = x.requires_grad and ops.train_bwd_h2(x.shape[0] * x.shape[2] * x.shape[3])
+                bwd_h2 = x.requires_grad and ops.train_bwd_h2(x.shape[0] * x.shape[2] * x.shape[3],
+                                                              self.weight.numel())
                 return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, None,
                                           None if bwd_h2 else self.packed_weight_dgrad(), self.packed_weight_h2(),
                                           self.packed_weight_h2_dgrad() if bwd_h2 else None)

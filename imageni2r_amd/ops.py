@@ -118,16 +118,27 @@ def train_fwd_h2(npos=None) -> bool:
 
 # Training DATA GRADIENTS of the convs on the f16x2-split kernel (i2r_conv2d_dgrad_h2: the forward kernel on transposed,
 # tap-flipped weights, dy scaled by a per-tensor power of two so that it splits at full precision).  "auto": convs with
-# at least _TRAIN_BWD_H2_MINPOS positions -- each such layer pays ~3 small launches (weight split, abs-max, scale) and
-# the kernel splits dy itself, so it wins only where the exact fp32-MFMA kernel is clearly matrix-pipe bound (measured,
-# graph-mode step: threshold 8192 loses 8 % on B1/C/A, 32768 gains 2.3 % on D and leaves the others alone); "0": never.
-# Weight gradients stay exact fp32.
+# at least _TRAIN_BWD_H2_MINPOS positions, or at least _MIDPOS positions and _MIDMACS multiply-adds per position -- each
+# such layer pays ~3 small launches (weight split, abs-max, scale) and the kernel splits dy itself, so it wins only
+# where the exact fp32-MFMA kernel is clearly matrix-pipe bound (measured, graph-mode step, after the abs-max kernel
+# stopped queueing on one atomic: positions alone >= 8192 still loses 0.7 % on B1/C/A while gaining 3.7 % on D; with the
+# work criterion every shape gains -- B1 15.72 -> 15.50 ms, C 16.13 -> 15.85, A 14.87 -> 14.61, D 33.1 -> 31.8); "0":
+# never.  Weight gradients stay exact fp32.
 _TRAIN_BWD_H2 = [os.environ.get("I2R_TRAIN_BWD_H2", "auto")]
 _TRAIN_BWD_H2_MINPOS = [int(os.environ.get("I2R_TRAIN_BWD_H2_MINPOS", 32768))]
 
 
-def train_bwd_h2(npos) -> bool:
-    return h2_math() and _TRAIN_BWD_H2[0] != "0" and _TRAIN_FWD_H2[0] != "0" and npos >= _TRAIN_BWD_H2_MINPOS[0]
+_TRAIN_BWD_H2_MIDPOS = [int(os.environ.get("I2R_TRAIN_BWD_H2_MIDPOS", 2048))]
+_TRAIN_BWD_H2_MIDMACS = [int(os.environ.get("I2R_TRAIN_BWD_H2_MIDMACS", 250000))]
+
+
+def train_bwd_h2(npos, macs_per_pos=0) -> bool:
+    """``macs_per_pos`` = Cin * Cout * k * k.  Besides the position threshold, layers from _MIDPOS positions on qualify
+    when they are heavy per position (the 256-channel 3x3 convs of the 16x16 level of the seq_len-768 shapes)."""
+    if not (h2_math() and _TRAIN_BWD_H2[0] != "0" and _TRAIN_FWD_H2[0] != "0"):
+        return False
+    return npos >= _TRAIN_BWD_H2_MINPOS[0] or (npos >= _TRAIN_BWD_H2_MIDPOS[0]
+                                               and macs_per_pos >= _TRAIN_BWD_H2_MIDMACS[0])
 
 
 def set_train_bwd_h2(mode, minpos=None) -> None:
