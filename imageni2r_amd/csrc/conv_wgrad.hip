@@ -3,6 +3,7 @@
 // The reduction runs over positions; it is split over blockIdx.z (fp32 atomics into a zeroed dW) when a single pass
 // would leave CUs idle.  The bias gradient (row sums of dY) falls out of the dY tiles the first column of workgroups
 // stages anyway.  `accumulate` adds into dW/db instead of overwriting them (the caller's pre-zeroed gradient buffer).
+#include <cstdint>
 #include <cstdlib>
 #include "conv_common.h"
 #include "../../include/i2r_hip.h"
@@ -168,6 +169,245 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 from halo tiles
+// The kernel above gathers every im2col column with its own scalar loads and bound checks, nine times over for the nine
+// taps of a channel, and does one MFMA per wave between them: its loader is the bound (~40 TF).  Here a wave stages, per
+// chunk of 64 positions (R = 64 / W whole image rows of one sample), the input rows with their zero halo ONCE --
+// position-major in LDS, 32 channels wide -- and the 32 dY rows beside them, and the nine taps are nine shifted reads
+// of that one tile: 288 MFMAs per chunk per wave against 24 16-byte loads per lane.  The four waves of a workgroup own
+// the SAME 32 (co) x 32 (ci) x 9 (taps) output tile and take every fourth chunk of the workgroup's position range, each
+// out of its own LDS tiles (no workgroup barrier in the loop); their accumulators are summed in wave order through LDS
+// at the end, so a workgroup adds one tile -- in the (ci, tap) order of dW's rows, 256 consecutive bytes per store --
+// where four workgroups of the gather kernel would each add theirs.
+template <int W_>
+struct WgTile {
+  static constexpr int R = 64 / W_;                // image rows per chunk
+  static constexpr int XR = (R + 2) * (W_ + 2);    // positions of the halo tile
+  static constexpr int LD = 33;                    // floats per position (32 channels + 1: conflict-free b32 reads)
+  static constexpr int XF = XR * LD, YF = 64 * LD;
+  static constexpr int WAVE_F = XF + YF;           // floats of LDS per wave
+  static constexpr int NX = 32 * (R + 2) * (W_ / 4) / 64;  // 16-byte loads per lane and chunk: input rows
+  static constexpr int NY = 8;                              //                                   dY rows
+  static constexpr int LDS_BYTES = 4 * WAVE_F * 4;
+  static_assert(4 * WAVE_F >= 4 * 16 * 288 + 4 * 32, "the reduction space lives in the operand space");
+};
+
+template <int W_>
+__global__ __launch_bounds__(256) void conv_wgrad3_tile_kernel(WgradParams p) {
+  using T = WgTile<W_>;
+  constexpr int R = T::R, LD = T::LD, W2 = W_ + 2, Q = W_ / 4, NX = T::NX, NY = T::NY;
+  extern __shared__ float wg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  float* const Xs = wg_smem + wave * T::WAVE_F;
+  float* const Ys = Xs + T::XF;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int cpi = p.H / R;  // chunks per image
+  const long total = (long)p.B * cpi;
+  const long c_begin = (long)blockIdx.z * p.chunks_per_split;
+  long c_end = c_begin + p.chunks_per_split;
+  if (c_end > total) c_end = total;
+  float* const dw_out = p.dw + (long)blockIdx.z * p.slab_stride;
+  float* const db_out = p.slab_stride > 0 ? dw_out + (long)p.Cout * p.K : p.db;
+  const bool want_bias = p.db != nullptr && blockIdx.x == 0;
+
+  for (int i = lane; i < (R + 2) * 2 * LD; i += 64) {  // the halo columns stay zero; the rest is rewritten per chunk
+    const int row = i / (2 * LD), rest = i - row * 2 * LD, side = rest / LD;
+    Xs[(row * W2 + side * (W_ + 1)) * LD + (rest - side * LD)] = 0.0f;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum[NY];
+#pragma unroll
+  for (int e = 0; e < NY; ++e) bsum[e] = 0.0f;
+
+  float4 rx[NX], ry[NY];
+  auto load_chunk = [&](long c) {
+    const int b = (int)(c / cpi);
+    const int y0 = (int)(c - (long)b * cpi) * R;
+    const float* xb = p.x + ((long)b * p.Cin + ci0) * p.HW;
+    const float* yb = p.dy + ((long)b * p.Cout + co0) * p.HW + y0 * W_;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int id = lane + 64 * e, q = id % Q, row = (id / Q) % (R + 2), ci = id / (Q * (R + 2));
+      const int y = y0 - 1 + row;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (ci0 + ci < p.Cin && (unsigned)y < (unsigned)p.H)
+        v = *reinterpret_cast<const float4*>(xb + (long)ci * p.HW + y * W_ + q * 4);
+      rx[e] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NY; ++e) {
+      const int id = lane + 64 * e, q = id & 15, co = id >> 4;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (co0 + co < p.Cout) v = *reinterpret_cast<const float4*>(yb + (long)co * p.HW + q * 4);
+      ry[e] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int id = lane + 64 * e, q = id % Q, row = (id / Q) % (R + 2), ci = id / (Q * (R + 2));
+      float* d = Xs + (row * W2 + 1 + q * 4) * LD + ci;
+      d[0] = rx[e].x; d[LD] = rx[e].y; d[2 * LD] = rx[e].z; d[3 * LD] = rx[e].w;
+    }
+#pragma unroll
+    for (int e = 0; e < NY; ++e) {
+      const int id = lane + 64 * e, q = id & 15, co = id >> 4;
+      float* d = Ys + (q * 4) * LD + co;
+      d[0] = ry[e].x; d[LD] = ry[e].y; d[2 * LD] = ry[e].z; d[3 * LD] = ry[e].w;
+      bsum[e] += (ry[e].x + ry[e].y) + (ry[e].z + ry[e].w);
+    }
+  };
+  // lane (l31, h): A = dY[co = l31][position 2*ks + h], B = X[ci = l31][that position shifted by the tap]
+  const float* const ya = Ys + h * LD + l31;
+  const float* const xa = Xs + h * LD + l31;
+  auto fetch = [&](int ks, float& a, float (&b)[9]) {
+    const int pos = 2 * ks, r = pos / W_, x = pos % W_;
+    a = ya[pos * LD];
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int ts = 0; ts < 3; ++ts) b[tr * 3 + ts] = xa[((r + tr) * W2 + x + ts) * LD];
+  };
+
+  long c = c_begin + wave;
+  if (c < c_end) {
+    load_chunk(c);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero fill is behind us
+    store_chunk();
+  }
+  while (c < c_end) {
+    const long cn = c + 4;
+    if (cn < c_end) load_chunk(cn);  // in flight under the MFMAs of this chunk
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float a0, b0[9], a1, b1[9];
+    fetch(0, a0, b0);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      if (ks + 1 < 32) fetch(ks + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) b0[t] = b1[t];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (cn < c_end) store_chunk();
+    c = cn;
+  }
+
+  // The four partial tiles are summed in wave order (a fixed order: the result does not depend on timing), sixteen
+  // output rows at a time: every wave parks those rows of its accumulators in LDS side by side, then all 256 threads
+  // add the four copies of their elements and send the sums out -- consecutive threads, consecutive floats of dW.
+  float* const part = wg_smem;                   // [4 waves][16 rows][288 = 32 ci x 9 taps]
+  float* const bpart = wg_smem + 4 * 16 * 288;   // [4 waves][32 co]
+  const int ncol = (p.Cin - ci0 < 32 ? p.Cin - ci0 : 32) * 9;
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {
+    __syncthreads();  // operand tiles (ph 0) / the previous sixteen rows (ph 1) are read out
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = ph == 0 ? acc[t][4 * g + i] : acc[t][8 + 4 * g + i];
+          part[(wave * 16 + 8 * g + i + 4 * h) * 288 + l31 * 9 + t] = v;
+        }
+    __syncthreads();
+#pragma unroll 6
+    for (int e = 0; e < 18; ++e) {
+      const int idx = tid + 256 * e, row = idx / 288, col = idx - row * 288;
+      const float v = ((part[idx] + part[4608 + idx]) + part[2 * 4608 + idx]) + part[3 * 4608 + idx];
+      const int co = co0 + 16 * ph + row;
+      if (co < p.Cout && col < ncol) {
+        float* dst = dw_out + (long)co * p.K + ci0 * 9 + col;
+        if (p.atomic)
+          atomicAdd(dst, v);
+        else
+          *dst = v;
+      }
+    }
+  }
+  if (want_bias) {  // the 16 lanes that share lane / 16 hold the 16 position quads of output channel 4 * e + lane / 16
+#pragma unroll
+    for (int e = 0; e < NY; ++e) {
+      float v = bsum[e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((lane & 15) == 0) bpart[wave * 32 + 4 * e + (lane >> 4)] = v;
+    }
+    __syncthreads();
+    if (tid < 32 && co0 + tid < p.Cout) {
+      const float v = ((bpart[tid] + bpart[32 + tid]) + bpart[64 + tid]) + bpart[96 + tid];
+      if (p.atomic)
+        atomicAdd(db_out + co0 + tid, v);
+      else
+        db_out[co0 + tid] = v;
+    }
+  }
+}
+
+// Position split of the tile kernel: one workgroup per CU at most (its LDS), so the split that minimises
+// rounds-of-256-workgroups x (chunks per wave + the epilogue's worth of about half a chunk).
+static bool wgrad_tile_shape_ok(int Cin, int H, int W, int Cout, long Npos, int ks) {
+  const char* sw = getenv("I2R_WGRAD_TILE");  // read per call: the A/B switch of the tests and probes
+  if ((sw && atoi(sw) == 0) || ks != 3) return false;
+  if (W != 8 && W != 16 && W != 32) return false;
+  if (H % (64 / W) != 0 || Cin < 32 || Cout < 32) return false;
+  static const long minpos = getenv("I2R_WGRAD_TILE_MINPOS") ? atol(getenv("I2R_WGRAD_TILE_MINPOS")) : 2048;
+  return Npos >= minpos;
+}
+
+static bool wgrad_tile_ok(const WgradParams& p, int ks) {  // + the 16-byte loads' alignment
+  return wgrad_tile_shape_ok(p.Cin, p.H, p.W, p.Cout, p.Npos, ks) &&
+         (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0;
+}
+
+static void wgrad_tile_plan(const WgradParams& p, int& chunks_per_split, int& nsplit) {
+  const long tiles = (long)i2r_cdiv(p.Cin, 32) * i2r_cdiv(p.Cout, 32);
+  const long total = p.Npos / 64;
+  long best_ns = 1;
+  double best = 1e30;
+  for (long ns = 1; ns <= total && ns <= 64; ++ns) {
+    const long cps = (total + ns - 1) / ns;
+    const long real_ns = (total + cps - 1) / cps;
+    const long rounds = (tiles * real_ns + 255) / 256;
+    const double t = (double)rounds * ((double)((cps + 3) / 4) + 0.5);
+    if (t < best - 1e-9) { best = t; best_ns = real_ns; }
+  }
+  chunks_per_split = (int)((total + best_ns - 1) / best_ns);
+  nsplit = (int)((total + chunks_per_split - 1) / chunks_per_split);
+}
+
+static void wgrad_tile_launch(const WgradParams& p, hipStream_t s) {
+  dim3 grid(i2r_cdiv(p.Cin, 32), i2r_cdiv(p.Cout, 32), p.nsplit);
+#define WG_TILE(W_)                                                                                          \
+  do {                                                                                                       \
+    auto kern = conv_wgrad3_tile_kernel<W_>;                                                                 \
+    static bool attr = false;                                                                                \
+    if (!attr) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                                WgTile<W_>::LDS_BYTES);                                                      \
+      attr = true;                                                                                           \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(256), WgTile<W_>::LDS_BYTES, s, p);                                  \
+  } while (0)
+  if (p.W == 8)
+    WG_TILE(8);
+  else if (p.W == 16)
+    WG_TILE(16);
+  else
+    WG_TILE(32);
+#undef WG_TILE
+}
+
 // Deterministic mode: out[i] (+)= slab[0][i] + slab[1][i] + ... in that fixed order; n = Cout*K (+ Cout for the bias
 // gradient, which sits behind dW in every slab and goes to its own output).
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride,
@@ -254,6 +494,16 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1,
                 accumulate ? 1 : 0, 0};
   hipStream_t s = (hipStream_t)stream;
+  if (wgrad_tile_ok(p, ksize)) {
+    wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+    if (p.nsplit > 1 && !p.atomic) {
+      (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
+      if (p.db) (void)hipMemsetAsync(p.db, 0, sizeof(float) * (size_t)p.Cout, s);
+      p.atomic = 1;
+    }
+    wgrad_tile_launch(p, s);
+    return i2r_check_launch("conv2d_wgrad");
+  }
   if (Cout <= 32)
     launch_wgrad<1, 4, 1, 1>(p, ksize, s);
   else if (p.K <= 32)
@@ -277,12 +527,22 @@ static int wgrad_variant(int K, int Cout, long Npos) {
 extern "C" long i2r_conv2d_wgrad_det_floats(int B, int Cin, int H, int W, int Cout, int ksize) {
   const int K = Cin * ksize * ksize;
   const long Npos = (long)B * H * W;
+  long need = 0;
   switch (wgrad_variant(K, Cout, Npos)) {
-    case 0: return wgrad_det_floats<1, 4, 1, 1>(K, Cout, Npos);
-    case 1: return wgrad_det_floats<4, 1, 1, 1>(K, Cout, Npos);
-    case 2: return wgrad_det_floats<2, 2, 2, 2>(K, Cout, Npos);
-    default: return wgrad_det_floats<2, 2, 1, 1>(K, Cout, Npos);
+    case 0: need = wgrad_det_floats<1, 4, 1, 1>(K, Cout, Npos); break;
+    case 1: need = wgrad_det_floats<4, 1, 1, 1>(K, Cout, Npos); break;
+    case 2: need = wgrad_det_floats<2, 2, 2, 2>(K, Cout, Npos); break;
+    default: need = wgrad_det_floats<2, 2, 1, 1>(K, Cout, Npos); break;
   }
+  if (wgrad_tile_shape_ok(Cin, H, W, Cout, Npos, ksize)) {  // the halo-tile kernel's slabs (it needs aligned operands;
+    WgradParams q{};                                        // the query covers whichever kernel the call then takes)
+    q.Cin = Cin; q.Cout = Cout; q.Npos = Npos;
+    int cps, ns;
+    wgrad_tile_plan(q, cps, ns);
+    const long t = (long)ns * ((long)Cout * K + Cout);
+    if (t > need) need = t;
+  }
+  return need;
 }
 
 extern "C" int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* dw, float* dbias, float* ws,
@@ -295,6 +555,20 @@ extern "C" int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* 
   I2R_REQUIRE(ws_floats >= need, "conv2d_wgrad_det: workspace of %ld floats, needs %ld", ws_floats, need);
   WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1, 0, 0};
   hipStream_t s = (hipStream_t)stream;
+  if (wgrad_tile_ok(p, ksize)) {
+    wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+    const long n_dw = (long)p.Cout * p.K, n_all = n_dw + (dbias ? p.Cout : 0);
+    p.dw = ws;
+    p.db = dbias ? ws : nullptr;
+    p.atomic = 0;
+    p.slab_stride = n_dw + p.Cout;
+    wgrad_tile_launch(p, s);
+    int nb = i2r_cdiv(n_all, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, s, ws, p.slab_stride, p.nsplit, dw, dbias,
+                       n_dw, n_all, accumulate);
+    return i2r_check_launch("conv2d_wgrad_det");
+  }
   switch (wgrad_variant(p.K, Cout, p.Npos)) {
     case 0: launch_wgrad_det<1, 4, 1, 1>(p, ksize, ws, dw, dbias, accumulate, s); break;
     case 1: launch_wgrad_det<4, 1, 1, 1>(p, ksize, ws, dw, dbias, accumulate, s); break;
