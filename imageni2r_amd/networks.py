@@ -11,6 +11,7 @@ The forward methods only sequence kernels: every arithmetic step is an entry poi
 from __future__ import annotations
 
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -141,9 +142,12 @@ class Conv2d(torch.nn.Module):
             if torch.is_grad_enabled() and ops.train_fwd_h2(x.shape[0] * x.shape[2] * x.shape[3]):
                 bwd_h2 = x.requires_grad and ops.train_bwd_h2(x.shape[0] * x.shape[2] * x.shape[3],
                                                               self.weight.numel())
+                self._train_modes = (True, bool(bwd_h2))  # which fp32 packs this layer does NOT need (_pack_plan)
                 return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, None,
                                           None if bwd_h2 else self.packed_weight_dgrad(), self.packed_weight_h2(),
                                           self.packed_weight_h2_dgrad() if bwd_h2 else None)
+            if torch.is_grad_enabled():
+                self._train_modes = (False, False)
             return ops.Conv2dFn.apply(x, self.weight, self.bias, residual, self.packed_weight(),
                                       self.packed_weight_dgrad() if torch.is_grad_enabled() else None)
         if residual is not None:
@@ -379,16 +383,29 @@ class DhariwalUNet(torch.nn.Module):
         fwd_too = not ops.train_fwd_h2()  # every forward on the f16x2 kernel: only the data-gradient layout is fp32
         if not (fwd_too or dgrad):
             return None
-        key = (tuple(c.weight.data_ptr() for c in convs), bool(dgrad), fwd_too)
-        ps = getattr(self, "_packset", None)
-        if ps is None or ps[0] != key:
+        # A layer whose last training forward ran on the f16x2 kernel needs no fp32 forward pack, and none of the
+        # data-gradient layout either if its data gradient runs there too (Conv2d.forward records both).  Unknown
+        # (first step) = pack both; a layer that changes its mind packs on the fly (packed_weight's key check).
+        if ops.train_fwd_h2_enabled() and not os.environ.get("I2R_PACK_ALL"):
+            modes = tuple(getattr(c, "_train_modes", (False, False)) for c in convs)
+        else:
+            modes = tuple((False, False) for _ in convs)
+        key = (tuple(c.weight.data_ptr() for c in convs), bool(dgrad), fwd_too, modes)
+        # every plan made stays alive: captured graphs hold raw pointers into its pool (a short last batch has other
+        # modes than the full ones, and its capture must not free the pool the full-batch graph replays from)
+        sets = self.__dict__.setdefault("_packsets", {})
+        ps = sets.get(key)
+        if ps is None:
             dev = convs[0].weight.device
             blk = ops._lib.query("i2r_conv2d_pack_block_floats")
             jobs = []
-            for c in convs:
+            for c, (f_h2, b_h2) in zip(convs, modes):
                 Cout, Cin, k, _ = c.weight.shape
-                for dg in ([0] if fwd_too else []) + ([1] if dgrad else []):
+                for dg in ([0] if fwd_too and not f_h2 else []) + ([1] if dgrad and not b_h2 else []):
                     jobs.append((c, dg, ops._lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, dg)))
+            if not jobs:
+                sets[key] = ps = (key, [], [], None, None, 0, None)
+                return ps
             pool = torch.empty(sum((n + 3) // 4 * 4 for _, _, n in jobs), dtype=torch.float32, device=dev)
             rows, bmap, views, off = [], [], [], 0
             for t, (c, dg, n) in enumerate(jobs):
@@ -401,7 +418,7 @@ class DhariwalUNet(torch.nn.Module):
             table = torch.tensor(rows, dtype=torch.int64).to(dev)
             bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
             ps = (key, jobs, views, table, bmap_t, len(bmap), pool)
-            self._packset = ps
+            sets[key] = ps
         return ps
 
     def pack_all_weights(self, dgrad=True):
@@ -412,6 +429,8 @@ class DhariwalUNet(torch.nn.Module):
         if ps is None:
             return
         _, jobs, views, table, bmap_t, nblocks, _ = ps
+        if not jobs:
+            return
         ops.pack_multi(table, bmap_t, nblocks)
         for (c, dg, _), v in zip(jobs, views):
             k3 = (c.weight.data_ptr(), c.weight._version, ops.pack_epoch())

@@ -321,6 +321,45 @@ def test_graphed_train_step_matches_eager():
     assert len(set(np.round(lg, 6))) > 1  # noise / sigma draws differ between replays
 
 
+def test_pack_plan_skips_the_fp32_layouts_f16x2_layers_do_not_read(monkeypatch):
+    """pack_all_weights packs, per step, only the fp32 layouts some kernel reads: layers whose forward (and data
+    gradient) ran on the f16x2 kernels drop out of the plan after the first step.  Same weights, bit for bit, as with
+    every layout packed (I2R_PACK_ALL=1) -- deterministic mode, replayed graph, batch big enough that the tiny net's
+    8x8 level crosses the f16x2 thresholds."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep, TS2img_Karras, ops as iops
+    from imageni2r_amd.networks import Conv2d
+    iops.set_deterministic(True)
+    runs = []
+    try:
+        for pack_all in ("1", None):
+            if pack_all:
+                monkeypatch.setenv("I2R_PACK_ALL", pack_all)
+            else:
+                monkeypatch.delenv("I2R_PACK_ALL", raising=False)
+            torch.manual_seed(0)
+            m = TS2img_Karras(tiny_args(device=DEV, batch_size=512), DEV)
+            O.perturb_zero_init(m.net.state_dict(), seed=1234)
+            m = m.to(DEV).train()
+            opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0,
+                             ema=(m.model_ema, m.net))
+            step = GraphedTrainStep(m, opt)
+            gen = torch.Generator().manual_seed(11)
+            for it in range(3):
+                _, mask = m.ts_to_img_with_mask(torch.rand(512, 24, 3, generator=gen).to(DEV))
+                loss = step(m.ts_to_img(torch.rand(512, 24, 3, generator=gen).to(DEV)), mask)
+            assert np.isfinite(loss.item())
+            net = m.net.model
+            convs = [c for c in net.modules() if isinstance(c, Conv2d) and c.weight is not None]
+            jobs = net._pack_plan(dgrad=True)[1]
+            runs.append((len(jobs), len(convs), [p.detach().cpu().clone() for p in m.net.parameters()]))
+    finally:
+        iops.set_deterministic(False)
+    (n_all, n_convs, p_all), (n_few, _, p_few) = runs
+    assert n_all == 2 * n_convs and n_few < n_all, (n_all, n_few, n_convs)
+    for a, b in zip(p_all, p_few):
+        assert torch.equal(a, b)
+
+
 def test_ema_scope_between_graphed_steps(monkeypatch):
     """Evaluation inside the pointer-swapped ``ema_scope`` between replayed training steps: it samples with the shadow
     weights the fused optimiser tail has been updating, gives exactly what the reference's copy sequence gives, and

@@ -1,13 +1,14 @@
 #!/bin/bash
 # GPU-box script: graph-replayed train step of the given workloads with an environment switch off and on.
-#   tools/train_ab.sh SWITCH "OFF ON" WORKLOAD...     e.g.  tools/train_ab.sh I2R_WGRAD_TILE "0 1" B1_weather96 D_etth1_768
+#   tools/train_ab.sh SWITCH "OFF ON" WORKLOAD...   (a value "unset" removes the variable)     e.g.  tools/train_ab.sh I2R_WGRAD_TILE "0 1" B1_weather96 D_etth1_768
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 SW=$1; VALS=$2; shift 2
 mkdir -p gpurun_out/ab
 for WL in "$@"; do
   for V in $VALS; do
-    env $SW=$V timeout -k 10 200 python3 bench.py --mode train --workload $WL --steps 30 --warmup 5 > gpurun_out/ab/$WL.$V.json 2> gpurun_out/ab/$WL.$V.err || { echo "$WL $SW=$V failed"; tail -5 gpurun_out/ab/$WL.$V.err; exit 1; }
+    if [ "$V" = unset ]; then E="-u $SW"; else E="$SW=$V"; fi
+    env $E timeout -k 10 200 python3 bench.py --mode train --workload $WL --steps 30 --warmup 5 > gpurun_out/ab/$WL.$V.json 2> gpurun_out/ab/$WL.$V.err || { echo "$WL $SW=$V failed"; tail -5 gpurun_out/ab/$WL.$V.err; exit 1; }
     python3 - "$WL" "$SW=$V" gpurun_out/ab/$WL.$V.json <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
