@@ -57,6 +57,7 @@ SIGNATURES = {
     "i2r_attention_fwd_h2": [P, P, I, I, I, I, P],
     "i2r_attention_fwd_h2_lse": [P, P, P, I, I, I, P],
     "i2r_attention_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
+    "i2r_attention_bwd_h2": [P, P, P, P, P, P, P, I, I, I, P],
     "i2r_pos_embedding_f32": [P, P, I, I, I, P],
     "i2r_linear_fwd_f32": [P, P, P, P, P, I, I, I, I, P],
     "i2r_linear_bwd_f32": [P, P, P, P, P, P, I, I, I, P],

@@ -675,3 +675,332 @@ extern "C" int i2r_attention_bwd_f32(const float* qkv, const float* out, const f
   }
   return i2r_check_launch("attention_bwd");
 }
+
+// ------------------------------------------------------------------------------------- backward on the f16 MFMA
+// The same two kernels with every product on the half-precision matrix cores in the f16x2 split (operands hi + lo in
+// fp16, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate): 48 (dk, dv) and 36 (dq) MFMAs of 32 cycles per
+// 32 x 32 tile where the fp32 kernels issue 128 and 96 of 64 cycles.  Gradients are far below fp16's range, so
+//   dA' = dA * s        s = the power of two that puts max|dA| into [2^13, 2^14)  (i2r_absmax_pow2_scale_f32),
+//   dS' = P (dP' - delta') * 2^-10                      (|dS'| <= 2^11 max|v|: inside fp16 for |v| < 32),
+// and dk, dv, dq are scaled back exactly at the end.  A value that leaves the range comes out as inf / NaN, never as
+// a finite wrong number; the optimiser skips such a step and the caller goes back to the exact kernels (train.py).
+// Chained products read the first product's ACCUMULATOR as their B operand (registers 8 s2 .. 8 s2 + 7 = k-step s2;
+// element j of lane half h is row 16 s2 + 8 (j >> 2) + 4 h + (j & 3)), so the other operand comes from an LDS image
+// stored in exactly that order ("perm" image); first products read [position][channel] rows ("rows" image).
+#define BROW 144                        // bytes per position row of a rows image: 64 channels x 2 B + 16 pad
+#define PROW 80                         // bytes per channel row of a perm image: 32 positions x 2 B + 16 pad
+#define ROWS_B (32 * BROW)              // one of hi / lo
+#define PERM_B (HD * PROW)
+#define DS_SCALE 0.0009765625f          // 2^-10
+#define K_SCALE 0.18033688011112042f    // 1/sqrt(64) * log2(e): scores in log2 units, softmax on exp2
+#define LOG2E 1.4426950408889634f
+
+// split of a plain fp32 value held in a register (not a product about to be folded into a conversion)
+__device__ __forceinline__ void r_split8(const float* v, ah8& hi, ah8& lo) { p_split8(v, hi, lo); }
+
+// One thread's share of staging a 64-channel x 32-position tile X[ch * cs + pos] as a rows image and a perm image.
+template <int NIT>
+struct TileRegs {
+  float r[NIT][8];
+  float4 q[NIT][2];
+};
+template <int NT, int NIT>
+__device__ __forceinline__ void tile_load(TileRegs<NIT>& g, const float* __restrict__ x, long cs, int tid, bool rows,
+                                          bool perm) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + NT * it;
+    if (rows) {
+      const int pos = item & 31, grp = item >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g.r[it][j] = x[(long)(8 * grp + j) * cs + pos];
+    }
+    if (perm) {
+      const int ch = item >> 2, piece = item & 3;
+      const float* src = x + (long)ch * cs + 16 * (piece >> 1) + 4 * (piece & 1);
+      g.q[it][0] = *reinterpret_cast<const float4*>(src);
+      g.q[it][1] = *reinterpret_cast<const float4*>(src + 8);
+    }
+  }
+}
+template <int NT, int NIT>
+__device__ __forceinline__ void tile_store(const TileRegs<NIT>& g, unsigned char* rows_img, unsigned char* perm_img,
+                                           int tid, float mul) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + NT * it;
+    ah8 hi, lo;
+    if (rows_img) {
+      const int pos = item & 31, grp = item >> 5;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = g.r[it][j] * mul;
+      a_split8(v, hi, lo);
+      *reinterpret_cast<ah8*>(rows_img + pos * BROW + grp * 16) = hi;
+      *reinterpret_cast<ah8*>(rows_img + ROWS_B + pos * BROW + grp * 16) = lo;
+    }
+    if (perm_img) {
+      const int ch = item >> 2, piece = item & 3;
+      float v[8] = {g.q[it][0].x * mul, g.q[it][0].y * mul, g.q[it][0].z * mul, g.q[it][0].w * mul,
+                    g.q[it][1].x * mul, g.q[it][1].y * mul, g.q[it][1].z * mul, g.q[it][1].w * mul};
+      a_split8(v, hi, lo);
+      *reinterpret_cast<ah8*>(perm_img + ch * PROW + piece * 16) = hi;
+      *reinterpret_cast<ah8*>(perm_img + PERM_B + ch * PROW + piece * 16) = lo;
+    }
+  }
+}
+// acc += A B in the f16x2 split: A = (ah, al), B = (bh, bl)
+__device__ __forceinline__ void mma3(f32x16& acc, ah8 ah, ah8 al, ah8 bh, ah8 bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+}
+
+#define DKV_STAGE (4 * ROWS_B + 4 * PERM_B + 256)  // Q rows, dA rows, Q perm, dA perm (hi + lo each), lse[32], delta[32]
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_h2_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta,
+                                                                  const float* __restrict__ dout,
+                                                                  const float* __restrict__ scale,
+                                                                  float* __restrict__ dqkv, int heads, int T) {
+  constexpr int NT = 64 * QW, NIT = 256 / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bwd_lds[];  // 2 stages
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;  // row (d, sel) at base + (3 d + sel) T
+  float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
+  const int key0 = (blockIdx.x * QW + wave) * 32;
+  const float sc = scale[0], isc = scale[1];
+
+  // this wave's 32 keys as B operands: lane = key, element j of k-step s = channel 16 s + 8 h + j
+  ah8 kh[4], kl[4], vh[4], vl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float kv[8], vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 16 * s + 8 * h + j;
+      kv[j] = base[(long)(3 * d + 1) * T + key0 + l31] * K_SCALE;
+      vv[j] = base[(long)(3 * d + 2) * T + key0 + l31];
+    }
+    a_split8(kv, kh[s], kl[s]);
+    a_split8(vv, vh[s], vl[s]);
+  }
+  f32x16 dK[2], dV[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dK[t][r] = dV[t][r] = 0.0f;
+
+  TileRegs<NIT> gq, ga;
+  float rl = 0.0f, rd = 0.0f;
+  auto stage_load = [&](int q0) {
+    tile_load<NT, NIT>(gq, base + q0, 3L * T, tid, true, true);
+    tile_load<NT, NIT>(ga, dab + q0, (long)T, tid, true, true);
+    if (tid < 32) {
+      rl = lse[(long)bh * T + q0 + tid];
+      rd = delta[(long)bh * T + q0 + tid];
+    }
+  };
+  auto stage_store = [&](int buf) {
+    unsigned char* st = bwd_lds + buf * DKV_STAGE;
+    tile_store<NT, NIT>(gq, st, st + 4 * ROWS_B, tid, 1.0f);
+    tile_store<NT, NIT>(ga, st + 2 * ROWS_B, st + 4 * ROWS_B + 2 * PERM_B, tid, sc);
+    if (tid < 32) {
+      float* ls = reinterpret_cast<float*>(st + 4 * ROWS_B + 4 * PERM_B);
+      ls[tid] = rl * LOG2E;
+      ls[32 + tid] = rd * sc;
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const int ntiles = T / 32;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const unsigned char* st = bwd_lds + (qt & 1) * DKV_STAGE;
+    if (qt + 1 < ntiles) stage_load((qt + 1) * 32);
+    const unsigned char* Qr = st;
+    const unsigned char* Ar = st + 2 * ROWS_B;
+    const unsigned char* Qp = st + 4 * ROWS_B;
+    const unsigned char* Ap = st + 4 * ROWS_B + 2 * PERM_B;
+    const float* ls = reinterpret_cast<const float*>(st + 4 * ROWS_B + 4 * PERM_B);
+    // S (log2 units) and dP': rows = query, cols = this lane's key
+    f32x16 sa, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = l31 * BROW + s * 32 + h * 16;
+      mma3(sa, *reinterpret_cast<const ah8*>(Qr + off), *reinterpret_cast<const ah8*>(Qr + ROWS_B + off), kh[s], kl[s]);
+      mma3(dp, *reinterpret_cast<const ah8*>(Ar + off), *reinterpret_cast<const ah8*>(Ar + ROWS_B + off), vh[s], vl[s]);
+    }
+    float pv[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float pr = __builtin_amdgcn_exp2f(sa[r] - ls[q]);
+      pv[r] = pr;
+      ds[r] = pr * (dp[r] - ls[32 + q]) * DS_SCALE;
+    }
+    // dV' += dA' P,  dK' += Q dS'   (reduction over the 32 queries = the accumulator rows above)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      ah8 ph, pl, sh, sl;
+      r_split8(pv + 8 * s2, ph, pl);
+      r_split8(ds + 8 * s2, sh, sl);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int off = (t * 32 + l31) * PROW + (2 * s2 + h) * 16;
+        mma3(dV[t], *reinterpret_cast<const ah8*>(Ap + off), *reinterpret_cast<const ah8*>(Ap + PERM_B + off), ph, pl);
+        mma3(dK[t], *reinterpret_cast<const ah8*>(Qp + off), *reinterpret_cast<const ah8*>(Qp + PERM_B + off), sh, sl);
+      }
+    }
+    if (qt + 1 < ntiles) stage_store((qt + 1) & 1);  // the other stage: its readers finished before the last barrier
+    __syncthreads();
+  }
+  const float ck = 0.125f * isc * (1.0f / DS_SCALE);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dbase[(long)(3 * d + 1) * T + key0 + l31] = dK[t][r] * ck;
+      dbase[(long)(3 * d + 2) * T + key0 + l31] = dV[t][r] * isc;
+    }
+}
+
+#define DQ_STAGE (4 * ROWS_B + 2 * PERM_B)  // K rows, V rows, K perm (hi + lo each)
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dq_h2_kernel(const float* __restrict__ qkv,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 const float* __restrict__ dout,
+                                                                 const float* __restrict__ scale,
+                                                                 float* __restrict__ dqkv, int heads, int T) {
+  constexpr int NT = 64 * QW, NIT = 256 / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char dq_lds[2 * DQ_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int C = heads * HD;
+  const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
+  const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
+  const int q0 = (blockIdx.x * QW + wave) * 32;
+  const float sc = scale[0], isc = scale[1];
+
+  // this wave's 32 queries as B operands: lane = query
+  ah8 qh[4], ql[4], dah[4], dal[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float qv[8], av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 16 * s + 8 * h + j;
+      qv[j] = base[(long)(3 * d + 0) * T + q0 + l31] * K_SCALE;
+      av[j] = dab[(long)d * T + q0 + l31] * sc;
+    }
+    a_split8(qv, qh[s], ql[s]);
+    a_split8(av, dah[s], dal[s]);
+  }
+  const float lse_q = lse[(long)bh * T + q0 + l31] * LOG2E;
+  const float del_q = delta[(long)bh * T + q0 + l31] * sc;
+  f32x16 dQ[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[t][r] = 0.0f;
+
+  TileRegs<NIT> gk, gv;
+  auto stage_load = [&](int k0) {
+    tile_load<NT, NIT>(gk, base + T + k0, 3L * T, tid, true, true);
+    tile_load<NT, NIT>(gv, base + 2 * T + k0, 3L * T, tid, true, false);
+  };
+  auto stage_store = [&](int buf) {
+    unsigned char* st = dq_lds + buf * DQ_STAGE;
+    tile_store<NT, NIT>(gk, st, st + 4 * ROWS_B, tid, 1.0f);
+    tile_store<NT, NIT>(gv, st + 2 * ROWS_B, nullptr, tid, 1.0f);
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const int ntiles = T / 32;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const unsigned char* st = dq_lds + (kt & 1) * DQ_STAGE;
+    if (kt + 1 < ntiles) stage_load((kt + 1) * 32);
+    const unsigned char* Kr = st;
+    const unsigned char* Vr = st + 2 * ROWS_B;
+    const unsigned char* Kp = st + 4 * ROWS_B;
+    // S^T (log2 units) and dP'^T: rows = key, cols = this lane's query
+    f32x16 sa, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = l31 * BROW + s * 32 + h * 16;
+      mma3(sa, *reinterpret_cast<const ah8*>(Kr + off), *reinterpret_cast<const ah8*>(Kr + ROWS_B + off), qh[s], ql[s]);
+      mma3(dp, *reinterpret_cast<const ah8*>(Vr + off), *reinterpret_cast<const ah8*>(Vr + ROWS_B + off), dah[s], dal[s]);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(sa[r] - lse_q) * (dp[r] - del_q) * DS_SCALE;
+    // dQ' += K dS'^T  (reduction over the 32 keys = the accumulator rows above)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      ah8 sh, sl;
+      r_split8(ds + 8 * s2, sh, sl);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int off = (t * 32 + l31) * PROW + (2 * s2 + h) * 16;
+        mma3(dQ[t], *reinterpret_cast<const ah8*>(Kp + off), *reinterpret_cast<const ah8*>(Kp + PERM_B + off), sh, sl);
+      }
+    }
+    if (kt + 1 < ntiles) stage_store((kt + 1) & 1);
+    __syncthreads();
+  }
+  const float cq = 0.125f * isc * (1.0f / DS_SCALE);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dbase[(long)(3 * d + 0) * T + q0 + l31] = dQ[t][r] * cq;
+    }
+}
+
+// The f16x2 form of i2r_attention_bwd_f32 for T a multiple of 128 (four waves = 128 keys / queries per workgroup).
+// scale: device float[2] {s, 1/s} from i2r_absmax_pow2_scale_f32 over dout.  All pointers 16-byte aligned.
+extern "C" int i2r_attention_bwd_h2(const float* qkv, const float* out, const float* lse, const float* dout,
+                                    float* dqkv, float* delta_ws, const float* scale, int B, int heads, int T,
+                                    i2r_stream_t stream) {
+  I2R_REQUIRE(qkv && out && lse && dout && dqkv && delta_ws && scale && B > 0 && heads > 0,
+              "attention_bwd_h2: bad argument");
+  I2R_REQUIRE(T >= 128 && T % 128 == 0, "attention_bwd_h2: T=%d must be a multiple of 128", T);
+  I2R_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)dout)) & 15) == 0, "attention_bwd_h2: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  long total = (long)B * heads * T;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(i2r_cdiv(total, 256)), dim3(256), 0, s, out, dout, delta_ws, heads, T,
+                     total);
+#define BWD_GO(QW_)                                                                                                 \
+  do {                                                                                                              \
+    auto kern = attn_bwd_dkv_h2_kernel<QW_>;                                                                        \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE);     \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 2 * DKV_STAGE, s, qkv, lse, delta_ws, \
+                       dout, scale, dqkv, heads, T);                                                                \
+    hipLaunchKernelGGL(attn_bwd_dq_h2_kernel<QW_>, dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 0, s, qkv, lse, \
+                       delta_ws, dout, scale, dqkv, heads, T);                                                      \
+  } while (0)
+  BWD_GO(4);
+#undef BWD_GO
+  return i2r_check_launch("attention_bwd_h2");
+}

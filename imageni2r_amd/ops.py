@@ -606,12 +606,33 @@ def attention_fwd(qkv, heads, save_lse=False, presplit=False):
     return out, lse
 
 
+# Attention BACKWARD on the f16x2-split kernels (i2r_attention_bwd_h2): sequences of 128 positions and more (T % 128
+# == 0), whenever training forwards may run on f16x2 kernels at all -- a non-finite gradient switches both back to the
+# exact fp32 kernels (GraphedTrainStep.check_range).  I2R_ATTN_BWD_H2=0: always the fp32 kernels.
+_ATTN_BWD_H2 = [os.environ.get("I2R_ATTN_BWD_H2", "auto")]
+
+
+def set_attn_bwd_h2(mode) -> None:
+    mode = {True: "auto", False: "0"}.get(mode, mode)
+    if mode not in ("auto", "0"):
+        raise ValueError(mode)
+    _ATTN_BWD_H2[0] = mode
+
+
+def attn_bwd_h2(T) -> bool:
+    return _ATTN_BWD_H2[0] != "0" and train_fwd_h2_enabled() and T >= 128 and T % 128 == 0
+
+
 def attention_bwd(qkv, out, lse, dout, heads):
     _chk(dout, "dout")
     B, C3 = qkv.shape[0], qkv.shape[1]
     T = qkv.numel() // (B * C3)
     dqkv = torch.empty_like(qkv)
     ws = torch.empty((B * heads * T,), dtype=torch.float32, device=qkv.device)
+    if attn_bwd_h2(T) and qkv.data_ptr() % 16 == 0 and dout.data_ptr() % 16 == 0:
+        _lib.call("i2r_attention_bwd_h2", _p(qkv), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws),
+                  _p(absmax_pow2_scale(dout)), B, heads, T, _stream())
+        return dqkv
     _lib.call("i2r_attention_bwd_f32", _p(qkv), _p(out), _p(lse), _p(dout), _p(dqkv), _p(ws), B, heads, T, _stream())
     return dqkv
 

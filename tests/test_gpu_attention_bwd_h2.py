@@ -1,0 +1,72 @@
+"""AttentionOp.backward + the einsum backward (models/networks.py:121-126, :184) on the f16x2-split kernels
+(i2r_attention_bwd_h2) against torch autograd in fp64 and against the exact fp32 kernels, through the C-ABI: T = 128 ...
+1024, one to eight heads, gradients of ordinary size and eight orders of magnitude below fp16's range (the power-of-two
+scaling), large scores.  Tolerance 3e-5 max-relative and RMS-relative per q / k / v gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+def _err(got, ref):
+    g, r = got.double(), ref.double()
+    e_max = float((g - r).abs().max() / r.abs().max().clamp_min(1e-300))
+    e_rms = float((g - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt().clamp_min(1e-300))
+    return max(e_max, e_rms)
+
+
+def _reference(qkv, da, heads):
+    B, C3, T = qkv.shape
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = qr.reshape(B * heads, 64, 3, T).unbind(2)
+    w = torch.einsum("ncq,nck->nqk", q, k / 8.0).softmax(dim=2)
+    torch.einsum("nqk,nck->ncq", w, v).reshape(B, C3 // 3, T).backward(da.double())
+    return qr.grad
+
+
+@pytest.mark.parametrize("B,heads,T", [(2, 2, 256), (1, 4, 1024), (3, 1, 128), (1, 2, 384), (2, 8, 256)])
+@pytest.mark.parametrize("gscale", [1.0, 3e-7])
+@pytest.mark.parametrize("qscale", [1.0, 3.0])
+def test_f16x2_backward_against_fp64_and_fp32_kernels(B, heads, T, gscale, qscale):
+    from imageni2r_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + heads * 10 + T)
+    C = 64 * heads
+    qkv = torch.randn(B, 3 * C, T, device="cuda", generator=g) * qscale
+    da = torch.randn(B, C, T, device="cuda", generator=g) * gscale
+    ref = _reference(qkv, da, heads)
+    a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
+    assert ops.attn_bwd_h2(T)
+    got = ops.attention_bwd(qkv, a, lse, da, heads)
+    ops.set_attn_bwd_h2(False)
+    try:
+        exact = ops.attention_bwd(qkv, a, lse, da, heads)
+    finally:
+        ops.set_attn_bwd_h2(True)
+    r5, g5, e5 = (t.reshape(B * heads, 64, 3, T) for t in (ref, got, exact))
+    for sel, name in enumerate("qkv"):
+        e = _err(g5[:, :, sel], r5[:, :, sel])
+        assert e < TOL, (name, e)
+        assert _err(g5[:, :, sel], e5[:, :, sel]) < TOL, name
+    assert torch.isfinite(got).all()
+
+
+def test_dispatch_keeps_short_sequences_and_the_off_switch_on_the_fp32_kernels():
+    from imageni2r_amd import ops
+    assert not ops.attn_bwd_h2(64) and not ops.attn_bwd_h2(16) and not ops.attn_bwd_h2(192) and ops.attn_bwd_h2(256)
+    prev = ops._TRAIN_FWD_H2[0]
+    ops.set_train_fwd_h2("0")  # the range fall-back of GraphedTrainStep.check_range: everything exact again
+    try:
+        assert not ops.attn_bwd_h2(256)
+    finally:
+        ops.set_train_fwd_h2(prev)
+
+
+def test_c_abi_rejects_what_the_kernel_does_not_cover():
+    from imageni2r_amd import _lib
+    x = torch.zeros(3 * 64 * 64, device="cuda")
+    p = lambda t: t.data_ptr()  # noqa: E731
+    with pytest.raises(_lib.I2RError):
+        _lib.call("i2r_attention_bwd_h2", p(x), p(x), p(x), p(x), p(x), p(x), p(x), 1, 1, 64, None)
+    with pytest.raises(_lib.I2RError):
+        _lib.call("i2r_attention_bwd_h2", p(x), p(x), p(x), p(x), p(x), p(x), None, 1, 1, 128, None)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random-shape check of the TRAINING kernels against torch autograd in fp64: conv forward (fp32 MFMA), data gradient
 (fp32 and f16x2 form), weight + bias gradient (atomic and deterministic slab form), GroupNorm forward / backward in its
-fused modes (scale-shift, SiLU), attention forward / backward.
+fused modes (scale-shift, SiLU), attention forward / backward (fp32 and f16x2 kernels, gradients down to 1e-8).
 
     python tools/train_fuzz.py [cases=200] [seed=0]
 """
@@ -111,7 +111,7 @@ for it in range(N):
         C = 64 * heads
         what = f"attn B{B} heads{heads} T{H * H}"
         qkv = torch.randn(B, 3 * C, H, H, device=dev, generator=g) * float(rng.uniform(0.5, 2.5))
-        da = torch.randn(B, C, H, H, device=dev, generator=g)
+        da = torch.randn(B, C, H, H, device=dev, generator=g) * float(10.0 ** rng.uniform(-8, 0))
         qr = qkv.double().requires_grad_(True)
         q, kk, v = qr.reshape(B * heads, 64, 3, H * H).unbind(2)
         wgt = torch.einsum("ncq,nck->nqk", q, kk / 8.0).softmax(dim=2)
@@ -119,7 +119,12 @@ for it in range(N):
         ref.backward(da.double())
         a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
         check("attn_fwd_train", a, ref.detach(), what)
-        check("attn_bwd", ops.attention_bwd(qkv, a, lse, da, heads), qr.grad, what)
+        check("attn_bwd", ops.attention_bwd(qkv, a, lse, da, heads), qr.grad, what)  # f16x2 kernels when T % 128 == 0
+        ops.set_attn_bwd_h2(False)
+        try:
+            check("attn_bwd_f32", ops.attention_bwd(qkv, a, lse, da, heads), qr.grad, what)
+        finally:
+            ops.set_attn_bwd_h2(True)
         if ops.attention_h2_ok(H * H):
             check("attn_fwd_h2", ops.attention_fwd(qkv, heads)[0], ref.detach(), what)
 print(f"{N} cases, failures {bad}; worst errors:", {k: f"{v:.1e}" for k, v in sorted(worst.items())})
