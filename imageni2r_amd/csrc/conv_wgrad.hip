@@ -3,6 +3,7 @@
 // The reduction runs over positions; it is split over blockIdx.z (fp32 atomics into a zeroed dW) when a single pass
 // would leave CUs idle.  The bias gradient (row sums of dY) falls out of the dY tiles the first column of workgroups
 // stages anyway.  `accumulate` adds into dW/db instead of overwriting them (the caller's pre-zeroed gradient buffer).
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include "conv_common.h"
@@ -408,6 +409,163 @@ static void wgrad_tile_launch(const WgradParams& p, hipStream_t s) {
 #undef WG_TILE
 }
 
+// ------------------------------------------------------------------------------------------------ 1x1, vector loader
+// dW[co][ci] = sum_n dY[co][n] X[ci][n] is a plain product of two position-contiguous matrices; at the shapes of the
+// path its outputs are few (49 k - 200 k) and its reduction long, so the position split that fills the chip is paid in
+// atomics -- measured here at ~0.2 per ns device-wide (they execute memory-side, behind the per-XCD L2s): 128 x 256
+// tiles, ideal for the matrix cores, lost to the gather kernel (0.43-0.84x) because few tiles force a deep split.  So:
+// the gather kernel's 64 x 64 tile (a wave 32 x 32), but fed by 16-byte loads along the positions in chunks of 32,
+// prefetched into registers under the previous chunk's MFMAs and stored position-major (odd pitch: conflict-free both
+// ways) -- no per-element index arithmetic -- and a split chosen against the atomics' cost (wgrad_tile1_plan).
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1_tile_kernel(WgradParams p) {
+  constexpr int PC = 32, LDA = BM + 1, LDB = BN + 1;
+  constexpr int TM = BM / 64, TN = BN / 64;    // 32-wide tiles per wave (waves 2 x 2)
+  constexpr int NA = BM * PC / 4 / 256, NB = BN * PC / 4 / 256;
+  __shared__ float As[PC * LDA];
+  __shared__ float Bs[PC * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
+  const long total = p.Npos / PC;
+  const long c_begin = (long)blockIdx.z * p.chunks_per_split;
+  long c_end = c_begin + p.chunks_per_split;
+  if (c_end > total) c_end = total;
+  float* const dw_out = p.dw + (long)blockIdx.z * p.slab_stride;
+  float* const db_out = p.slab_stride > 0 ? dw_out + (long)p.Cout * p.K : p.db;
+  const bool want_bias = p.db != nullptr && blockIdx.x == 0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float bsum[NA];
+#pragma unroll
+  for (int e = 0; e < NA; ++e) bsum[e] = 0.0f;
+
+  float4 ra[NA], rb[NB];
+  auto load_chunk = [&](long c) {
+    const long n0 = c * PC;
+    const int b = (int)(n0 / p.HW);
+    const int pos = (int)(n0 - (long)b * p.HW);  // HW % 32 == 0: a chunk never leaves its sample
+    const float* yb = p.dy + ((long)b * p.Cout + co0) * p.HW + pos;
+    const float* xb = p.x + ((long)b * p.Cin + ci0) * p.HW + pos;
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+      const int id = tid + 256 * e, q = id & 7, co = id >> 3;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (co0 + co < p.Cout) v = *reinterpret_cast<const float4*>(yb + (long)co * p.HW + q * 4);
+      ra[e] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int id = tid + 256 * e, q = id & 7, ci = id >> 3;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (ci0 + ci < p.Cin) v = *reinterpret_cast<const float4*>(xb + (long)ci * p.HW + q * 4);
+      rb[e] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+      const int id = tid + 256 * e, q = id & 7, co = id >> 3;
+      float* d = As + (q * 4) * LDA + co;
+      d[0] = ra[e].x; d[LDA] = ra[e].y; d[2 * LDA] = ra[e].z; d[3 * LDA] = ra[e].w;
+      bsum[e] += (ra[e].x + ra[e].y) + (ra[e].z + ra[e].w);
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int id = tid + 256 * e, q = id & 7, ci = id >> 3;
+      float* d = Bs + (q * 4) * LDB + ci;
+      d[0] = rb[e].x; d[LDB] = rb[e].y; d[2 * LDB] = rb[e].z; d[3 * LDB] = rb[e].w;
+    }
+  };
+
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk();
+    __syncthreads();
+    for (long c = c_begin; c < c_end; ++c) {
+      if (c + 1 < c_end) load_chunk(c + 1);  // in flight under this chunk's MFMAs
+      mma_chunk<2, 2, TM, TN, PC>(As, Bs, LDA, LDB, acc, wm, wn, l31, h);
+      __syncthreads();  // everyone is done reading this chunk
+      if (c + 1 < c_end) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int ci = ci0 + (wn * TN + tn) * 32 + l31;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout) {
+          float* dst = dw_out + (long)co * p.K + ci;
+          if (p.atomic)
+            atomicAdd(dst, acc[tm][tn][r]);
+          else
+            *dst = acc[tm][tn][r];
+        }
+      }
+  }
+  if (want_bias) {  // the 8 lanes that share id / 8 hold the 8 position quads of output channel id / 8
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+      float v = bsum[e];
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int co = co0 + ((tid + 256 * e) >> 3);
+      if ((tid & 7) == 0 && co < p.Cout) {
+        if (p.atomic)
+          atomicAdd(db_out + co, v);
+        else
+          db_out[co] = v;
+      }
+    }
+  }
+}
+
+static bool wgrad_tile1_shape_ok(int Cin, int H, int W, int Cout, long Npos, int ks) {
+  const char* sw = getenv("I2R_WGRAD_TILE");  // 0: gather kernel everywhere, 3: only the 3x3 tile kernel
+  if ((sw && (atoi(sw) == 0 || atoi(sw) == 3)) || ks != 1) return false;
+  if ((H * W) % 32 != 0 || Cin < 64 || Cout < 64) return false;
+  static const long minpos = getenv("I2R_WGRAD_TILE_MINPOS") ? atol(getenv("I2R_WGRAD_TILE_MINPOS")) : 2048;
+  return Npos >= minpos;
+}
+static bool wgrad_tile1_ok(const WgradParams& p, int ks) {
+  return wgrad_tile1_shape_ok(p.Cin, p.H, p.W, p.Cout, p.Npos, ks) && (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0;
+}
+
+// Position split against the atomics' cost: a split of ns costs (chunks / ns) * t_chunk of matrix work per workgroup
+// and outputs * ns atomics device-wide; the sum is least at ns = sqrt(chunks * t_chunk * rate / outputs).  t_chunk
+// ~2 us (32 positions of a 64 x 64 tile incl. its two barriers and its share of L2 traffic; swept 0.5 - 5), rate ~0.2 atomics per ns (measured: 16.7 M in 80 us).
+static void wgrad_tile1_plan(const WgradParams& p, int& chunks_per_split, int& nsplit) {
+  const long tiles = (long)i2r_cdiv(p.Cin, 64) * i2r_cdiv(p.Cout, 64);
+  const long total = p.Npos / 32;
+  static const double t_chunk = getenv("I2R_WGRAD1_TCHUNK") ? atof(getenv("I2R_WGRAD1_TCHUNK")) : 2.0;
+  static const double rate = getenv("I2R_WGRAD1_RATE") ? atof(getenv("I2R_WGRAD1_RATE")) : 2.0e5;  // per us
+  double ns_d = sqrt((double)total * t_chunk * rate / ((double)p.Cin * p.Cout));
+  long ns = (long)(ns_d + 0.5);
+  if (ns * tiles > 2048) ns = 2048 / tiles;  // no more than ~8 workgroups per CU
+  if (ns > total) ns = total;
+  if (ns < 1) ns = 1;
+  chunks_per_split = (int)((total + ns - 1) / ns);
+  nsplit = (int)((total + chunks_per_split - 1) / chunks_per_split);
+}
+
+static void wgrad_tile1_launch(const WgradParams& p, hipStream_t s) {
+  dim3 grid(i2r_cdiv(p.Cin, 64), i2r_cdiv(p.Cout, 64), p.nsplit);
+  hipLaunchKernelGGL((conv_wgrad1_tile_kernel<64, 64>), grid, dim3(256), 0, s, p);
+}
+
 // Deterministic mode: out[i] (+)= slab[0][i] + slab[1][i] + ... in that fixed order; n = Cout*K (+ Cout for the bias
 // gradient, which sits behind dW in every slab and goes to its own output).
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride,
@@ -494,14 +652,21 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1,
                 accumulate ? 1 : 0, 0};
   hipStream_t s = (hipStream_t)stream;
-  if (wgrad_tile_ok(p, ksize)) {
-    wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+  const bool t3 = wgrad_tile_ok(p, ksize), t1 = !t3 && wgrad_tile1_ok(p, ksize);
+  if (t3 || t1) {
+    if (t3)
+      wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+    else
+      wgrad_tile1_plan(p, p.chunks_per_split, p.nsplit);
     if (p.nsplit > 1 && !p.atomic) {
       (void)hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.Cout * p.K, s);
       if (p.db) (void)hipMemsetAsync(p.db, 0, sizeof(float) * (size_t)p.Cout, s);
       p.atomic = 1;
     }
-    wgrad_tile_launch(p, s);
+    if (t3)
+      wgrad_tile_launch(p, s);
+    else
+      wgrad_tile1_launch(p, s);
     return i2r_check_launch("conv2d_wgrad");
   }
   if (Cout <= 32)
@@ -542,6 +707,14 @@ extern "C" long i2r_conv2d_wgrad_det_floats(int B, int Cin, int H, int W, int Co
     const long t = (long)ns * ((long)Cout * K + Cout);
     if (t > need) need = t;
   }
+  if (wgrad_tile1_shape_ok(Cin, H, W, Cout, Npos, ksize)) {
+    WgradParams q{};
+    q.Cin = Cin; q.Cout = Cout; q.Npos = Npos;
+    int cps, ns;
+    wgrad_tile1_plan(q, cps, ns);
+    const long t = (long)ns * ((long)Cout * K + Cout);
+    if (t > need) need = t;
+  }
   return need;
 }
 
@@ -555,14 +728,21 @@ extern "C" int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* 
   I2R_REQUIRE(ws_floats >= need, "conv2d_wgrad_det: workspace of %ld floats, needs %ld", ws_floats, need);
   WgradParams p{x, dy, dw, dbias, B, Cin, H, W, Cout, H * W, Cin * ksize * ksize, (long)B * H * W, 0, 1, 0, 0};
   hipStream_t s = (hipStream_t)stream;
-  if (wgrad_tile_ok(p, ksize)) {
-    wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+  const bool t3 = wgrad_tile_ok(p, ksize), t1 = !t3 && wgrad_tile1_ok(p, ksize);
+  if (t3 || t1) {
+    if (t3)
+      wgrad_tile_plan(p, p.chunks_per_split, p.nsplit);
+    else
+      wgrad_tile1_plan(p, p.chunks_per_split, p.nsplit);
     const long n_dw = (long)p.Cout * p.K, n_all = n_dw + (dbias ? p.Cout : 0);
     p.dw = ws;
     p.db = dbias ? ws : nullptr;
     p.atomic = 0;
     p.slab_stride = n_dw + p.Cout;
-    wgrad_tile_launch(p, s);
+    if (t3)
+      wgrad_tile_launch(p, s);
+    else
+      wgrad_tile1_launch(p, s);
     int nb = i2r_cdiv(n_all, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, s, ws, p.slab_stride, p.nsplit, dw, dbias,
