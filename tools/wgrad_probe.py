@@ -2,7 +2,8 @@
 """Times the 3x3 weight gradient at the training shapes of B1 / D (batch 32) with the halo-tile kernel on and off
 (I2R_WGRAD_TILE, read per call): microseconds and algorithmic TFLOP/s per shape.
 
-    python tools/wgrad_probe.py [batch=32] [ksize=3]      (ksize 1: the gather kernel alone)
+    python tools/wgrad_probe.py [batch=32] [ksize=3] [small]
+small: the low-resolution layers that stay on the gather kernel (compare I2R_WGRAD_PLAN=old, a per-process switch).
 """
 import os
 import sys
@@ -38,6 +39,9 @@ if KS == 1:
     SHAPES = [(128, 384, 32), (128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 768, 16), (256, 256, 16),
               (128, 384, 16), (128, 128, 16), (512, 256, 16), (256, 768, 8), (256, 256, 8), (512, 256, 8),
               (512, 1536, 4), (512, 512, 4)]
+if len(sys.argv) > 3 and sys.argv[3] == "small":
+    SHAPES = ([(256, 256, 4), (512, 256, 4), (512, 512, 4), (512, 512, 2), (1024, 512, 2), (768, 256, 4)] if KS == 3 else
+              [(512, 1536, 2), (512, 512, 2), (256, 768, 4), (256, 256, 4), (512, 1536, 4), (512, 256, 4)])
 print("%-22s %10s %8s %10s %8s %7s" % ("shape", "gather us", "TF", "tile us", "TF", "x"), flush=True)
 for Cin, Cout, S in SHAPES:
     x = torch.randn(B, Cin, S, S, device="cuda")
