@@ -454,6 +454,10 @@ static void gn_launch(const GnP& p, hipStream_t s) {
   const int n = (p.C / p.G) * p.HW;
   const bool reg_ok = p.sh >= 2 && n <= 16384 && (((uintptr_t)p.x) & 15) == 0 &&
                       (((uintptr_t)p.y) & 15) == 0 && (!BWD || ((((uintptr_t)p.dy) | ((uintptr_t)p.add)) & 15) == 0);
+  // Few groups (training batches: 32 samples x 32 groups = one wave per SIMD in the 64-lane forms, every load's
+  // latency exposed): the whole workgroup takes one group, four times the waves with a quarter of the loads each.
+  const char* wide = getenv("I2R_GN_WIDE");
+  const bool few = groups <= 2048 && !(wide && wide[0] == '0');
 #define GN_GO(LPG, NV)                                                                                          \
   do {                                                                                                          \
     dim3 grid(i2r_cdiv(groups, 256 / LPG));                                                                     \
@@ -477,11 +481,11 @@ static void gn_launch(const GnP& p, hipStream_t s) {
   } else if (n <= 512) {
     GN_GO(64, 2);
   } else if (n <= 1024) {
-    GN_GO(64, 4);
+    if (few && n > 512) GN_GO(256, 1); else GN_GO(64, 4);
   } else if (n <= 2048) {
-    GN_GO(64, 8);
+    if (few) GN_GO(256, 2); else GN_GO(64, 8);
   } else if (n <= 4096) {
-    GN_GO(64, 16);
+    if (few) GN_GO(256, 4); else GN_GO(64, 16);
   } else if (n <= 8192) {
     GN_GO(256, 8);
   } else {
