@@ -15,7 +15,7 @@
 //     the element offset of every im2col element a thread fetches are LOOP-INVARIANT: they live in registers as
 //     buffer voffsets, the chunk advance is the instruction's scalar soffset, and out-of-image taps carry an
 //     out-of-range voffset that the buffer unit turns into 0.0 -- the main loop has no address VALU at all;
-//   * register-staged double buffering: the loads of chunk c+1 are in flight under the MFMAs of chunk c;
+//   * register-staged prefetch, two chunks deep: the loads of chunks c+1 and c+2 are in flight under the MFMAs of c;
 //   * split-K over blockIdx.z (deterministic: partial slabs + a fused reduce/bias/residual pass) for the low-resolution
 //     layers whose M x N tile count cannot fill 256 CUs.
 #include "conv_common.h"
@@ -35,7 +35,7 @@ struct Conv2Params {
   long Npos;
   int chunks_per_split, nsplit;
   long slab_stride;   // elements between split-K slabs
-  int ablate;         // tuning only (I2R_CONV_ABLATE): 1 skip loads, 2 skip LDS stores, 4 skip barriers, 8 skip epilogue
+  int ablate;         // tuning only (I2R_CONV_ABLATE): 8 skip the epilogue
 };
 
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -118,24 +118,29 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Conv2Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 ra[NA];
-  float rb[NB];
-  auto load_chunk = [&](int c) {
+  // Register stages: the loads of chunks c+1 and c+2 are in flight while chunk c is multiplied.  One chunk is only
+  // 9 (3x3) or 8 (1x1) MFMAs per wave -- ~550 cycles against ~2000 of load latency -- and the low-resolution layers
+  // that come here in training run two or three workgroups per CU, so with a single chunk in flight (the first form
+  // of this loop) every iteration waited for memory: 1.2 us per chunk.
+  constexpr int DEPTH = 3;
+  f32x4 ra[DEPTH][NA];
+  float rb[DEPTH][NB];
+  auto load_chunk = [&](int c, f32x4 (&qa)[NA], float (&qb)[NB]) {
     unsigned sA = (unsigned)c * stepA, sB = (unsigned)c * stepB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) ra[j] = buf_load_f32x4(rA, voffA[j], sA);
+    for (int j = 0; j < NA; ++j) qa[j] = buf_load_f32x4(rA, voffA[j], sA);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = buf_load_f32(rB, voffB[j], sB);
+    for (int j = 0; j < NB; ++j) qb[j] = buf_load_f32(rB, voffB[j], sB);
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const f32x4 (&qa)[NA], const float (&qb)[NB]) {
     float* a = As + buf * BKC * LDA;
     float* b = Bs + buf * BKC * LDB;
 #pragma unroll
     for (int j = 0; j < NA; ++j)
-      if (ldsA[j] >= 0) *reinterpret_cast<f32x4*>(a + ldsA[j]) = ra[j];
+      if (ldsA[j] >= 0) *reinterpret_cast<f32x4*>(a + ldsA[j]) = qa[j];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-      if (ldsB[j] >= 0) b[ldsB[j]] = rb[j];
+      if (ldsB[j] >= 0) b[ldsB[j]] = qb[j];
   };
 
   const int total_chunks = p.Kpad / BKC;
@@ -143,24 +148,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Conv2Params p) {
   int c_end = c_begin + p.chunks_per_split;
   if (c_end > total_chunks) c_end = total_chunks;
   if (c_begin < c_end) {
-    load_chunk(c_begin);
-    store_chunk(0);
-    __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-      int cur = (c - c_begin) & 1;
-      if (c + 1 < c_end && !(p.ablate & 1)) load_chunk(c + 1);
-      if (p.ablate & 16) {  // tuning only: bare MFMA stream, no LDS operand reads
+    // The loop body has no conditional loads (past the end the LAST chunk is fetched again and never used), so the
+    // compiler can count: each store waits with a partial vmcnt that leaves the two younger chunks in flight.
+    const int c_last = c_end - 1;
+    load_chunk(c_begin, ra[0], rb[0]);
+    load_chunk(c_begin + 1 < c_end ? c_begin + 1 : c_last, ra[1], rb[1]);
+    for (int c = c_begin; c < c_end; c += DEPTH) {
 #pragma unroll
-        for (int ks = 0; ks < BKC / 2; ++ks)
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[0], ra[0][0], acc[tm][tn], 0, 0, 0);
-      } else
-      mma_chunk<WM, WN, TM, TN, BKC>(As + cur * BKC * LDA, Bs + cur * BKC * LDB, LDA, LDB, acc, wm, wn, l31, h);
-      if (c + 1 < c_end && !(p.ablate & 2)) store_chunk(cur ^ 1);
-      if (!(p.ablate & 4)) __syncthreads();
+      for (int u = 0; u < DEPTH; ++u) {
+        const int cc = c + u;
+        if (cc < c_end) {  // uniform over the workgroup
+          const int cur = (cc - c_begin) & 1;
+          load_chunk(cc + 2 < c_end ? cc + 2 : c_last, ra[(u + 2) % DEPTH], rb[(u + 2) % DEPTH]);
+          // LDS buffer `cur` was last read by the MFMAs of chunk cc - 2; every wave finished them before it passed
+          // the barrier of chunk cc - 1
+          store_chunk(cur, ra[u], rb[u]);
+          __syncthreads();
+          mma_chunk<WM, WN, TM, TN, BKC>(As + cur * BKC * LDA, Bs + cur * BKC * LDB, LDA, LDB, acc, wm, wn, l31, h);
+        }
+      }
     }
   }
 
