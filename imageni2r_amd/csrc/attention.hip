@@ -759,7 +759,7 @@ __device__ __forceinline__ void mma3(f32x16& acc, ah8 ah, ah8 al, ah8 bh, ah8 bl
 #define DKV_STAGE (4 * ROWS_B + 4 * PERM_B + 256)  // Q rows, dA rows, Q perm, dA perm (hi + lo each), lse[32], delta[32]
 
 template <int QW>
-__global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_h2_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * QW, QW == 4 ? 2 : 1) void attn_bwd_dkv_h2_kernel(const float* __restrict__ qkv,
                                                                   const float* __restrict__ lse,
                                                                   const float* __restrict__ delta,
                                                                   const float* __restrict__ dout,
@@ -817,13 +817,17 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_h2_kernel(const float
     }
   };
 
+  // Four waves: the next tile's loads are in flight under this tile's MFMAs (two LDS stages).  Two waves (T = 64, two
+  // tiles in all): each thread stages twice as much, and holding that across the MFMAs would spill -- load, store,
+  // compute, one stage.
+  constexpr bool PIPE = QW == 4;
   stage_load(0);
   stage_store(0);
   __syncthreads();
   const int ntiles = T / 32;
   for (int qt = 0; qt < ntiles; ++qt) {
-    const unsigned char* st = bwd_lds + (qt & 1) * DKV_STAGE;
-    if (qt + 1 < ntiles) stage_load((qt + 1) * 32);
+    const unsigned char* st = bwd_lds + (PIPE ? (qt & 1) : 0) * DKV_STAGE;
+    if (PIPE && qt + 1 < ntiles) stage_load((qt + 1) * 32);
     const unsigned char* Qr = st;
     const unsigned char* Ar = st + 2 * ROWS_B;
     const unsigned char* Qp = st + 4 * ROWS_B;
@@ -860,8 +864,17 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_h2_kernel(const float
         mma3(dK[t], *reinterpret_cast<const ah8*>(Qp + off), *reinterpret_cast<const ah8*>(Qp + PERM_B + off), sh, sl);
       }
     }
-    if (qt + 1 < ntiles) stage_store((qt + 1) & 1);  // the other stage: its readers finished before the last barrier
-    __syncthreads();
+    if (PIPE) {
+      if (qt + 1 < ntiles) stage_store((qt + 1) & 1);  // the other stage: its readers finished before the last barrier
+      __syncthreads();
+    } else {
+      __syncthreads();  // this tile is read out
+      if (qt + 1 < ntiles) {
+        stage_load((qt + 1) * 32);
+        stage_store(0);
+        __syncthreads();
+      }
+    }
   }
   const float ck = 0.125f * isc * (1.0f / DS_SCALE);
 #pragma unroll
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dkv_h2_kernel(const float
 #define DQ_STAGE (4 * ROWS_B + 2 * PERM_B)  // K rows, V rows, K perm (hi + lo each)
 
 template <int QW>
-__global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dq_h2_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * QW, QW == 4 ? 2 : 1) void attn_bwd_dq_h2_kernel(const float* __restrict__ qkv,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta,
                                                                  const float* __restrict__ dout,
@@ -927,13 +940,14 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dq_h2_kernel(const float*
     tile_store<NT, NIT>(gv, st + 2 * ROWS_B, nullptr, tid, 1.0f);
   };
 
+  constexpr bool PIPE = QW == 4;  // as in the dk / dv kernel
   stage_load(0);
   stage_store(0);
   __syncthreads();
   const int ntiles = T / 32;
   for (int kt = 0; kt < ntiles; ++kt) {
-    const unsigned char* st = dq_lds + (kt & 1) * DQ_STAGE;
-    if (kt + 1 < ntiles) stage_load((kt + 1) * 32);
+    const unsigned char* st = dq_lds + (PIPE ? (kt & 1) : 0) * DQ_STAGE;
+    if (PIPE && kt + 1 < ntiles) stage_load((kt + 1) * 32);
     const unsigned char* Kr = st;
     const unsigned char* Vr = st + 2 * ROWS_B;
     const unsigned char* Kp = st + 4 * ROWS_B;
@@ -961,8 +975,17 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dq_h2_kernel(const float*
         mma3(dQ[t], *reinterpret_cast<const ah8*>(Kp + off), *reinterpret_cast<const ah8*>(Kp + PERM_B + off), sh, sl);
       }
     }
-    if (kt + 1 < ntiles) stage_store((kt + 1) & 1);
-    __syncthreads();
+    if (PIPE) {
+      if (kt + 1 < ntiles) stage_store((kt + 1) & 1);
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (kt + 1 < ntiles) {
+        stage_load((kt + 1) * 32);
+        stage_store(0);
+        __syncthreads();
+      }
+    }
   }
   const float cq = 0.125f * isc * (1.0f / DS_SCALE);
 #pragma unroll
@@ -974,14 +997,15 @@ __global__ __launch_bounds__(64 * QW, 2) void attn_bwd_dq_h2_kernel(const float*
     }
 }
 
-// The f16x2 form of i2r_attention_bwd_f32 for T a multiple of 128 (four waves = 128 keys / queries per workgroup).
+// The f16x2 form of i2r_attention_bwd_f32 for T a multiple of 64 (four waves = 128 keys / queries per workgroup when
+// T % 128 == 0, else two).
 // scale: device float[2] {s, 1/s} from i2r_absmax_pow2_scale_f32 over dout.  All pointers 16-byte aligned.
 extern "C" int i2r_attention_bwd_h2(const float* qkv, const float* out, const float* lse, const float* dout,
                                     float* dqkv, float* delta_ws, const float* scale, int B, int heads, int T,
                                     i2r_stream_t stream) {
   I2R_REQUIRE(qkv && out && lse && dout && dqkv && delta_ws && scale && B > 0 && heads > 0,
               "attention_bwd_h2: bad argument");
-  I2R_REQUIRE(T >= 128 && T % 128 == 0, "attention_bwd_h2: T=%d must be a multiple of 128", T);
+  I2R_REQUIRE(T >= 64 && T % 64 == 0, "attention_bwd_h2: T=%d must be a multiple of 64", T);
   I2R_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)dout)) & 15) == 0, "attention_bwd_h2: operands must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   long total = (long)B * heads * T;
@@ -1000,7 +1024,10 @@ extern "C" int i2r_attention_bwd_h2(const float* qkv, const float* out, const fl
     hipLaunchKernelGGL(attn_bwd_dq_h2_kernel<QW_>, dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 0, s, qkv, lse, \
                        delta_ws, dout, scale, dqkv, heads, T);                                                      \
   } while (0)
-  BWD_GO(4);
+  if (T % 128 == 0)
+    BWD_GO(4);
+  else
+    BWD_GO(2);
 #undef BWD_GO
   return i2r_check_launch("attention_bwd_h2");
 }

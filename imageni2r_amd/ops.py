@@ -606,10 +606,11 @@ def attention_fwd(qkv, heads, save_lse=False, presplit=False):
     return out, lse
 
 
-# Attention BACKWARD on the f16x2-split kernels (i2r_attention_bwd_h2): sequences of 128 positions and more (T % 128
+# Attention BACKWARD on the f16x2-split kernels (i2r_attention_bwd_h2): sequences of 64 positions and more (T % 64
 # == 0), whenever training forwards may run on f16x2 kernels at all -- a non-finite gradient switches both back to the
 # exact fp32 kernels (GraphedTrainStep.check_range).  I2R_ATTN_BWD_H2=0: always the fp32 kernels.
 _ATTN_BWD_H2 = [os.environ.get("I2R_ATTN_BWD_H2", "auto")]
+_ATTN_BWD_H2_MINT = int(os.environ.get("I2R_ATTN_BWD_H2_MINT", 64))  # A/B: 128 keeps T = 64 on the fp32 kernels
 
 
 def set_attn_bwd_h2(mode) -> None:
@@ -620,7 +621,7 @@ def set_attn_bwd_h2(mode) -> None:
 
 
 def attn_bwd_h2(T) -> bool:
-    return _ATTN_BWD_H2[0] != "0" and train_fwd_h2_enabled() and T >= 128 and T % 128 == 0
+    return _ATTN_BWD_H2[0] != "0" and train_fwd_h2_enabled() and T >= _ATTN_BWD_H2_MINT and T % 64 == 0
 
 
 def attention_bwd(qkv, out, lse, dout, heads):

@@ -179,7 +179,7 @@ int i2r_attention_bwd_f32(const float* qkv, const float* out, const float* lse, 
 
 /* The same backward on the f16x2-split matrix-core path (models/networks.py:121-126, :184 like i2r_attention_bwd_f32):
  * every product as three f16 MFMAs with fp32 accumulation, dout scaled into fp16's range by `scale` = device float[2]
- * {s, 1/s} from i2r_absmax_pow2_scale_f32 over dout and scaled back exactly.  T a multiple of 128; qkv and dout
+ * {s, 1/s} from i2r_absmax_pow2_scale_f32 over dout and scaled back exactly.  T a multiple of 64; qkv and dout
  * 16-byte aligned.  A value that leaves fp16's range comes out non-finite, never finite and wrong. */
 int i2r_attention_bwd_h2(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                          float* delta_ws, const float* scale, int B, int heads, int T, i2r_stream_t stream);
