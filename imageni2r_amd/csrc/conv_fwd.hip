@@ -248,20 +248,26 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // Multi-tensor form: every conv weight of the network (forward and data-gradient layouts) in ONE launch.
 // table rows {w, wp, Cout, Cin, ksize, dgrad} (int64); blockmap {tensor, block} with PACK_BLOCK packed floats per block.
 #define PACK_BLOCK 4096
-#define PACK_LDS 8192
 __device__ __forceinline__ float pack_src(const float* __restrict__ w, int m, int k, int M, int K, int KK, int Cin,
                                           int dgrad) {
   if (m >= M || k >= K) return 0.0f;
   int c = k / KK, tap = k - c * KK;
   return dgrad ? w[((long)c * Cin + m) * KK + (KK - 1 - tap)] : w[((long)m * Cin + c) * KK + tap];
 }
-// A block owns PACK_BLOCK consecutive packed floats = a band of k-rows [k_lo, k_hi] of Wp.  It is a transpose, so the
-// band is gathered in SOURCE order (lanes along k, which is contiguous in OIHW for both layouts: forward reads
-// w[m][k_lo..k_hi], dgrad reads the (ci, tap) slab of one co back to front), staged in LDS with an odd row pitch, and
-// written out in packed order: both global sides are coalesced.
+// It is a transpose, done in 64 (k) x 64 (m) tiles through LDS so that BOTH global sides move 256 contiguous bytes per
+// wave: the first form gave every block a band of 4096 / M4 whole k-rows, which for the wide layers (M = 512: 8 rows)
+// read the source in 32-byte pieces -- 1.9 TB/s over B1's 70 M low-resolution weights.  Read order per layout:
+//   forward        : lanes along k (w[m][k0 ..] is contiguous in OIHW);
+//   dgrad, 1x1     : lanes along m (w[c][m0 ..] is contiguous: no transpose at all);
+//   dgrad, 3x3     : the (ci, tap) slab of each co the tile touches, front to back (64 ci x 9 taps contiguous), each
+//                    element dropped at its flipped tap's row.
+// A tensor keeps ceil(total / PACK_BLOCK) blocks (the host's block map); they stride over its ceil(Kpad / 64) x
+// ceil(M4 / 64) tiles.
+#define PT 64
+#define PTP 65
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __restrict__ table,
                                                                 const int2* __restrict__ blockmap) {
-  __shared__ float tile[PACK_LDS];
+  __shared__ float tile[PT * PTP];
   const int2 bm = blockmap[blockIdx.x];
   const long* e = table + 6L * bm.x;
   const float* w = (const float*)e[0];
@@ -271,26 +277,42 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long* __re
   const int KK = ks * ks, K = C * KK, bkc = ks == 3 ? 18 : 16;
   const int Kpad = (K + bkc - 1) / bkc * bkc, M4 = (M + 3) / 4 * 4;
   const long total = (long)Kpad * M4;
-  const long begin = (long)bm.y * PACK_BLOCK;
-  long end = begin + PACK_BLOCK;
-  if (end > total) end = total;
-  const int k_lo = (int)(begin / M4), k_hi = (int)((end - 1) / M4);
-  const int rows = k_hi - k_lo + 1, pitch = M4 | 1;
-  if ((long)rows * pitch <= PACK_LDS) {
-    const int n = rows * M4;
-    for (int j = threadIdx.x; j < n; j += 256) {
-      int m = j / rows, kk = j - m * rows;
-      tile[kk * pitch + m] = pack_src(w, m, k_lo + kk, M, K, KK, Cin, dgrad);
+  const int nb_t = (int)((total + PACK_BLOCK - 1) / PACK_BLOCK);  // blocks the host gave this tensor
+  const int tiles_m = (M4 + PT - 1) / PT, tiles_k = (Kpad + PT - 1) / PT;
+  const int tid = threadIdx.x;
+  for (int t = bm.y; t < tiles_m * tiles_k; t += nb_t) {
+    const int k0 = (t / tiles_m) * PT, m0 = (t % tiles_m) * PT;
+    __syncthreads();  // the previous tile is written out
+    if (dgrad && KK == 9) {
+      for (int j = tid; j < PT * PTP; j += 256) tile[j] = 0.0f;  // rows / columns the slabs do not reach (padding)
+      __syncthreads();
+      const int c_lo = k0 / 9, c_hi = (k0 + PT - 1) / 9;  // the co whose (ci, tap) slabs meet this tile's k rows
+      const int mw = (M - m0 < PT ? M - m0 : PT) * 9;     // floats of a slab inside this tile's m range
+      for (int c = c_lo; c <= c_hi && c < C; ++c) {
+        const float* src = w + ((long)c * Cin + m0) * 9;
+        for (int r = tid; r < mw; r += 256) {
+          const int mm = r / 9, tap = 8 - (r - 9 * mm), kk = c * 9 + tap - k0;
+          if (kk >= 0 && kk < PT) tile[kk * PTP + mm] = src[r];
+        }
+      }
+    } else if (dgrad) {  // 1x1: Wp[c][m] = w[c][m]
+#pragma unroll 4
+      for (int i = 0; i < PT * PT / 256; ++i) {
+        const int j = tid + 256 * i, mm = j & (PT - 1), kk = j >> 6;
+        tile[kk * PTP + mm] = pack_src(w, m0 + mm, k0 + kk, M, K, KK, Cin, 1);
+      }
+    } else {
+#pragma unroll 4
+      for (int i = 0; i < PT * PT / 256; ++i) {
+        const int j = tid + 256 * i, kk = j & (PT - 1), mm = j >> 6;
+        tile[kk * PTP + mm] = pack_src(w, m0 + mm, k0 + kk, M, K, KK, Cin, 0);
+      }
     }
     __syncthreads();
-    for (long i = begin + threadIdx.x; i < end; i += 256) {
-      int k = (int)(i / M4), m = (int)(i - (long)k * M4);
-      wp[i] = tile[(k - k_lo) * pitch + m];
-    }
-  } else {
-    for (long i = begin + threadIdx.x; i < end; i += 256) {
-      int k = (int)(i / M4), m = (int)(i - (long)k * M4);
-      wp[i] = pack_src(w, m, k, M, K, KK, Cin, dgrad);
+#pragma unroll 4
+    for (int i = 0; i < PT * PT / 256; ++i) {
+      const int j = tid + 256 * i, mm = j & (PT - 1), kk = j >> 6;
+      if (k0 + kk < Kpad && m0 + mm < M4) wp[(long)(k0 + kk) * M4 + m0 + mm] = tile[kk * PTP + mm];
     }
   }
 }
