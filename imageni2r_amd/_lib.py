@@ -35,6 +35,8 @@ SIGNATURES = {
     "i2r_conv2d_splitk_h2_floats": [I, I, I, I, I, I],
     "i2r_conv2d_fwd_h2": [P, P, P, P, P, P, L, I, I, I, I, I, I, I, P],
     "i2r_conv2d_pack_weight_h2_dgrad": [P, P, I, I, I, P],
+    "i2r_conv2d_pack_h2_block_pairs": [],
+    "i2r_conv2d_pack_h2_multi": [P, P, I, P],
     "i2r_conv2d_dgrad_h2": [P, P, P, P, P, L, I, I, I, I, I, I, P],
     "i2r_absmax_pow2_scale_f32": [P, L, P, P, P],
     "i2r_conv2d_fwd_h2_noalloc_max_floats": [],

@@ -643,30 +643,33 @@ __global__ void splitk_reduce_h2_kernel(const float* __restrict__ slabs, long sl
 // Packed split weights  Wp[chunk][co][hl][KC]  (f16, scaled by 2^6):
 //   3x3: chunk = r * nCB + cb (nCB = ceil(Cin/16)), k = s*16 + c  <-  w[co][cb*16 + c][r][s]
 //   1x1: chunk = cb (nCB = ceil(Cin/64)),            k = c         <-  w[co][cb*64 + c]
+__device__ __forceinline__ void pack_h2_elem(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout, int Cin,
+                                             int ks, int nCB, long i) {
+  const int KC = ks == 3 ? 48 : 64;
+  int k = (int)(i % KC);
+  long t = i / KC;
+  int co = (int)(t % Cout);
+  int chunk = (int)(t / Cout);
+  float v = 0.0f;
+  if (ks == 3) {
+    int r = chunk / nCB, cb = chunk % nCB;
+    int s = k / 16, c = cb * 16 + (k % 16);
+    if (c < Cin) v = w[((long)co * Cin + c) * 9 + r * 3 + s];
+  } else {
+    int c = chunk * 64 + k;
+    if (c < Cin) v = w[(long)co * Cin + c];
+  }
+  v *= WSCALE;
+  _Float16 hi, lo;
+  f16_split(v, hi, lo);
+  long base = ((long)chunk * Cout + co) * 2 * KC;
+  wp[base + k] = hi;
+  wp[base + KC + k] = lo;
+}
 __global__ void pack_weight_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout, int Cin,
                                       int ks, int nCB, long total) {
-  const int KC = ks == 3 ? 48 : 64;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int k = (int)(i % KC);
-    long t = i / KC;
-    int co = (int)(t % Cout);
-    int chunk = (int)(t / Cout);
-    float v = 0.0f;
-    if (ks == 3) {
-      int r = chunk / nCB, cb = chunk % nCB;
-      int s = k / 16, c = cb * 16 + (k % 16);
-      if (c < Cin) v = w[((long)co * Cin + c) * 9 + r * 3 + s];
-    } else {
-      int c = chunk * 64 + k;
-      if (c < Cin) v = w[(long)co * Cin + c];
-    }
-    v *= WSCALE;
-    _Float16 hi, lo;
-    f16_split(v, hi, lo);
-    long base = ((long)chunk * Cout + co) * 2 * KC;
-    wp[base + k] = hi;
-    wp[base + KC + k] = lo;
-  }
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    pack_h2_elem(w, wp, Cout, Cin, ks, nCB, i);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -692,29 +695,57 @@ extern "C" int i2r_conv2d_pack_weight_h2(const float* w, void* wp, int Cout, int
 // Packed split weights of the DATA-GRADIENT problem: dx = conv2d(dy, Wd), Wd[ci][co][r][s] = w[co][ci][2-r][2-s]
 // (the transposed, tap-flipped filter; autograd of conv2d w.r.t. its input): the forward layout above with the roles
 // of Cout and Cin swapped -- rows = ci (the output channels of this problem), k runs over (tap, co).
+__device__ __forceinline__ void pack_h2_dgrad_elem(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout,
+                                                   int Cin, int ks, int nCB, long i) {
+  const int KC = ks == 3 ? 48 : 64;
+  int k = (int)(i % KC);
+  long t = i / KC;
+  int ci = (int)(t % Cin);      // row of the packed matrix = output channel of the dgrad problem
+  int chunk = (int)(t / Cin);
+  float v = 0.0f;
+  if (ks == 3) {
+    int r = chunk / nCB, cb = chunk % nCB;
+    int s = k / 16, co = cb * 16 + (k % 16);
+    if (co < Cout) v = w[((long)co * Cin + ci) * 9 + (2 - r) * 3 + (2 - s)];
+  } else {
+    int co = chunk * 64 + k;
+    if (co < Cout) v = w[(long)co * Cin + ci];
+  }
+  v *= WSCALE;
+  _Float16 hi, lo;
+  f16_split(v, hi, lo);
+  long base = ((long)chunk * Cin + ci) * 2 * KC;
+  wp[base + k] = hi;
+  wp[base + KC + k] = lo;
+}
 __global__ void pack_weight_h2_dgrad_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout, int Cin,
                                             int ks, int nCB, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    pack_h2_dgrad_elem(w, wp, Cout, Cin, ks, nCB, i);
+}
+
+// Multi-tensor form (training: one launch per step instead of one or two per layer).  table rows {w, wp, Cout, Cin,
+// ksize, dgrad} (int64); blockmap {tensor, block}, a block = H2_PACK_BLOCK split pairs of that tensor.
+#define H2_PACK_BLOCK 4096
+__global__ __launch_bounds__(256) void pack_weight_h2_multi_kernel(const long* __restrict__ table,
+                                                                   const int2* __restrict__ blockmap) {
+  const int2 bm = blockmap[blockIdx.x];
+  const long* e = table + 6L * bm.x;
+  const float* w = (const float*)e[0];
+  _Float16* wp = (_Float16*)e[1];
+  const int Cout = (int)e[2], Cin = (int)e[3], ks = (int)e[4], dgrad = (int)e[5];
   const int KC = ks == 3 ? 48 : 64;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int k = (int)(i % KC);
-    long t = i / KC;
-    int ci = (int)(t % Cin);      // row of the packed matrix = output channel of the dgrad problem
-    int chunk = (int)(t / Cin);
-    float v = 0.0f;
-    if (ks == 3) {
-      int r = chunk / nCB, cb = chunk % nCB;
-      int s = k / 16, co = cb * 16 + (k % 16);
-      if (co < Cout) v = w[((long)co * Cin + ci) * 9 + (2 - r) * 3 + (2 - s)];
-    } else {
-      int co = chunk * 64 + k;
-      if (co < Cout) v = w[(long)co * Cin + ci];
-    }
-    v *= WSCALE;
-    _Float16 hi, lo;
-    f16_split(v, hi, lo);
-    long base = ((long)chunk * Cin + ci) * 2 * KC;
-    wp[base + k] = hi;
-    wp[base + KC + k] = lo;
+  const int red = dgrad ? Cout : Cin, rows = dgrad ? Cin : Cout;  // reduction / row channels of this layout
+  const int nCB = ks == 3 ? (red + 15) / 16 : (red + 63) / 64;
+  const long total = (long)(ks == 3 ? 3 : 1) * nCB * rows * KC;
+  const long begin = (long)bm.y * H2_PACK_BLOCK;
+  long end = begin + H2_PACK_BLOCK;
+  if (end > total) end = total;
+  for (long i = begin + threadIdx.x; i < end; i += 256) {
+    if (dgrad)
+      pack_h2_dgrad_elem(w, wp, Cout, Cin, ks, nCB, i);
+    else
+      pack_h2_elem(w, wp, Cout, Cin, ks, nCB, i);
   }
 }
 
@@ -728,6 +759,15 @@ extern "C" int i2r_conv2d_pack_weight_h2_dgrad(const float* w, void* wp, int Cou
   hipLaunchKernelGGL(pack_weight_h2_dgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)wp, Cout,
                      Cin, ksize, h2_ncb(Cout, ksize), total);
   return i2r_check_launch("pack_weight_h2_dgrad");
+}
+
+extern "C" int i2r_conv2d_pack_h2_block_pairs(void) { return H2_PACK_BLOCK; }
+
+extern "C" int i2r_conv2d_pack_h2_multi(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream) {
+  I2R_REQUIRE(table && blockmap && nblocks > 0, "pack_h2_multi: bad argument");
+  hipLaunchKernelGGL(pack_weight_h2_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const long*)table, (const int2*)blockmap);
+  return i2r_check_launch("pack_h2_multi");
 }
 
 // positions per workgroup: 256 (8 waves, one workgroup per CU) once that still gives every CU >= 2 workgroups of work,

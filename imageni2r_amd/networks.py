@@ -403,41 +403,70 @@ class DhariwalUNet(torch.nn.Module):
                 Cout, Cin, k, _ = c.weight.shape
                 for dg in ([0] if fwd_too and not f_h2 else []) + ([1] if dgrad and not b_h2 else []):
                     jobs.append((c, dg, ops._lib.query("i2r_conv2d_packed_floats", Cout, Cin, k, dg)))
-            if not jobs:
-                sets[key] = ps = (key, [], [], None, None, 0, None)
-                return ps
-            pool = torch.empty(sum((n + 3) // 4 * 4 for _, _, n in jobs), dtype=torch.float32, device=dev)
-            rows, bmap, views, off = [], [], [], 0
-            for t, (c, dg, n) in enumerate(jobs):
-                v = pool[off: off + n]
-                off += (n + 3) // 4 * 4
+            ps = [key, jobs, [], None, None, 0, None, None]
+            if jobs:
+                pool = torch.empty(sum((n + 3) // 4 * 4 for _, _, n in jobs), dtype=torch.float32, device=dev)
+                rows, bmap, views, off = [], [], [], 0
+                for t, (c, dg, n) in enumerate(jobs):
+                    v = pool[off: off + n]
+                    off += (n + 3) // 4 * 4
+                    Cout, Cin, k, _ = c.weight.shape
+                    rows.append([c.weight.data_ptr(), v.data_ptr(), Cout, Cin, k, dg])
+                    bmap.extend([t, b] for b in range((n + blk - 1) // blk))
+                    views.append(v)
+                ps[2:7] = [views, torch.tensor(rows, dtype=torch.int64).to(dev),
+                           torch.tensor(bmap, dtype=torch.int32).to(dev), len(bmap), pool]
+            # the split-f16 layouts of the layers that run on the f16x2 kernels, likewise in one launch
+            hjobs = []
+            for c, (f_h2, b_h2) in zip(convs, modes):
                 Cout, Cin, k, _ = c.weight.shape
-                rows.append([c.weight.data_ptr(), v.data_ptr(), Cout, Cin, k, dg])
-                bmap.extend([t, b] for b in range((n + blk - 1) // blk))
-                views.append(v)
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
-            ps = (key, jobs, views, table, bmap_t, len(bmap), pool)
+                if f_h2:
+                    hjobs.append((c, 0, ops._lib.query("i2r_conv2d_packed_h2_bytes", Cout, Cin, k)))
+                if b_h2 and dgrad:
+                    hjobs.append((c, 1, ops._lib.query("i2r_conv2d_packed_h2_bytes", Cin, Cout, k)))
+            if hjobs and not os.environ.get("I2R_PACK_H2_PER_LAYER"):
+                hblk = ops._lib.query("i2r_conv2d_pack_h2_block_pairs")
+                hpool = torch.empty(sum((n + 255) // 256 * 256 for _, _, n in hjobs), dtype=torch.uint8, device=dev)
+                rows, bmap, hviews, off = [], [], [], 0
+                for t, (c, dg, n) in enumerate(hjobs):
+                    v = hpool[off: off + n]
+                    off += (n + 255) // 256 * 256
+                    Cout, Cin, k, _ = c.weight.shape
+                    rows.append([c.weight.data_ptr(), v.data_ptr(), Cout, Cin, k, dg])
+                    bmap.extend([t, b] for b in range((n // 4 + hblk - 1) // hblk))
+                    hviews.append(v)
+                ps[7] = (hjobs, hviews, torch.tensor(rows, dtype=torch.int64).to(dev),
+                         torch.tensor(bmap, dtype=torch.int32).to(dev), len(bmap), hpool)
+            ps = tuple(ps)
             sets[key] = ps
         return ps
 
     def pack_all_weights(self, dgrad=True):
-        """Pack every conv weight (forward layout, and the data-gradient layout when ``dgrad``) in ONE launch into
-        persistent buffers and mark them current, so the following forward/backward launches no per-layer pack
-        kernels.  Call once per optimiser step (GraphedTrainStep does, inside its graph)."""
+        """Pack every conv weight some kernel of the coming step reads -- fp32 forward / data-gradient layouts in one
+        launch, split-f16 layouts in another -- into persistent buffers and mark them current, so the following
+        forward/backward launches no per-layer pack kernels.  Call once per optimiser step (GraphedTrainStep does,
+        inside its graph)."""
         ps = self._pack_plan(dgrad)
         if ps is None:
             return
-        _, jobs, views, table, bmap_t, nblocks, _ = ps
-        if not jobs:
-            return
-        ops.pack_multi(table, bmap_t, nblocks)
-        for (c, dg, _), v in zip(jobs, views):
-            k3 = (c.weight.data_ptr(), c.weight._version, ops.pack_epoch())
-            if dg:
-                c._wpd, c._wpd_key = v, k3
-            else:
-                c._wp, c._wp_key = v, k3
+        _, jobs, views, table, bmap_t, nblocks, _, h2 = ps
+        if jobs:
+            ops.pack_multi(table, bmap_t, nblocks)
+            for (c, dg, _), v in zip(jobs, views):
+                k3 = (c.weight.data_ptr(), c.weight._version, ops.pack_epoch())
+                if dg:
+                    c._wpd, c._wpd_key = v, k3
+                else:
+                    c._wp, c._wp_key = v, k3
+        if h2 is not None:
+            hjobs, hviews, htable, hbmap, hblocks, _ = h2
+            ops.pack_h2_multi(htable, hbmap, hblocks)
+            for (c, dg, _), v in zip(hjobs, hviews):
+                k3 = (c.weight.data_ptr(), c.weight._version, ops.pack_epoch())
+                if dg:
+                    c._wpdh, c._wpdh_key = v, k3
+                else:
+                    c._wph, c._wph_key = v, k3
 
     @staticmethod
     def _cat_in_place(x, skip, block):

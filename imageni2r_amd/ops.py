@@ -307,6 +307,10 @@ def pack_multi(table, blockmap, nblocks):
     _lib.call("i2r_conv2d_pack_multi_f32", _p(table), _p(blockmap), int(nblocks), _stream())
 
 
+def pack_h2_multi(table, blockmap, nblocks):
+    _lib.call("i2r_conv2d_pack_h2_multi", _p(table), _p(blockmap), int(nblocks), _stream())
+
+
 def _conv_packed(x, wp, bias, residual, Cout, k):
     B, Cin, H, W = x.shape
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)

@@ -88,6 +88,12 @@ int i2r_conv2d_fwd_h2(const float* x, const void* wp, const float* bias, const f
  * two s they are split at full precision and the result is scaled back (both exact). */
 int i2r_conv2d_pack_weight_h2_dgrad(const float* w /* OIHW */, void* wp, int Cout, int Cin, int ksize,
                                     i2r_stream_t stream);
+/* Both split-f16 packs for many layers in ONE launch (the training step packs every layer's weights once per step).
+ * table: device int64 rows {w, wp, Cout, Cin, ksize, dgrad} -- wp as for i2r_conv2d_pack_weight_h2 (dgrad 0) or
+ * i2r_conv2d_pack_weight_h2_dgrad (dgrad 1); blockmap: device int32 pairs {row, block}, a row needing
+ * ceil(pairs / i2r_conv2d_pack_h2_block_pairs()) blocks, pairs = i2r_conv2d_packed_h2_bytes(...) / 4. */
+int i2r_conv2d_pack_h2_block_pairs(void);
+int i2r_conv2d_pack_h2_multi(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream);
 int i2r_conv2d_dgrad_h2(const float* dy, const void* wpd, float* dx, const float* scale, float* splitk_ws,
                         long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize, i2r_stream_t stream);
 /* scale_out[0] = s = 2^(13 - floor(log2 max|x|)), scale_out[1] = 1/s (s = 1 when max|x| is 0 or not finite).

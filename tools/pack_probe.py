@@ -32,7 +32,7 @@ for h2fwd in (False, True):
         # build the plan without launching: pack_all_weights builds it lazily, so replicate its host checks first
         blk = ops._lib.query("i2r_conv2d_pack_block_floats")
         ops.new_pack_epoch()
-        key, jobs, views, table, bmap, nblocks, pool = net._pack_plan(dgrad=True)  # host only: nothing launched yet
+        key, jobs, views, table, bmap, nblocks, pool, _h2 = net._pack_plan(dgrad=True)  # host only: nothing launched yet
         rows = table.cpu().tolist()
         lo, hi = pool.data_ptr(), pool.data_ptr() + pool.numel() * 4
         assert len(rows) == len(jobs) == len(views)
