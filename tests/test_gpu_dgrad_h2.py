@@ -33,6 +33,29 @@ def test_absmax_pow2_scale(ops, mag):
         assert ops.absmax_pow2_scale(y).cpu().tolist() == [1.0, 1.0]
 
 
+def test_absmax_pow2_scale_back_to_back_large_and_small(ops):
+    """Many calls in a row on one stream sharing the scratch word: tensors from one element to 17 MB (1024
+    workgroups), unaligned starts, the peak in the first / last element -- every scale right, the scratch word zero
+    at the end."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    sizes = [1, 3, 64, 1000, 4097, 262144, 1 << 20, (1 << 22) + 5, 1 << 22]
+    xs, want = [], []
+    for rep in range(3):
+        for i, n in enumerate(sizes):
+            buf = torch.randn(n + 1, device=DEV, generator=g) * 10.0 ** (-((i + rep) % 9))
+            x = buf[1:] if (i + rep) % 2 else buf[:n]
+            x = x.contiguous() if not x.is_contiguous() else x
+            x[(0 if rep == 0 else n - 1)] *= 37.0
+            xs.append(x)
+    scales = [ops.absmax_pow2_scale(x) for x in xs]   # no synchronisation in between
+    torch.cuda.synchronize()
+    for x, s in zip(xs, scales):
+        peak = float(x.abs().max())
+        s0, s1 = s.tolist()
+        assert s0 * s1 == 1.0 and 2.0 ** 13 <= peak * s0 < 2.0 ** 14, (x.numel(), peak, s0)
+    assert int(ops._scale_scratch(xs[0].device).item()) == 0
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,k", [(4, 64, 64, 16, 3), (2, 128, 256, 8, 1), (32, 128, 128, 16, 3),
                                              (3, 96, 40, 4, 3), (2, 256, 128, 32, 3), (5, 12, 128, 16, 3),
                                              (2, 1024, 512, 2, 3), (7, 384, 128, 16, 1), (3, 24, 20, 6, 3)])
