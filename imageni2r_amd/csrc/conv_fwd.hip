@@ -35,6 +35,9 @@ struct Conv2Params {
   long Npos;
   int chunks_per_split, nsplit;
   long slab_stride;   // elements between split-K slabs
+  int slab_cn;        // 1: split-K slabs are laid out [co][n] (n = position over the whole batch) instead of NCHW: with
+                      // HW < 32 an NCHW tile leaves as 4*HW-byte pieces, once per split; [co][n] leaves as 128-byte runs
+                      // and the reduce pass scatters once
   int ablate;         // tuning only (I2R_CONV_ABLATE): 8 skip the epilogue
 };
 
@@ -195,6 +198,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Conv2Params p) {
         if (use_res && ok) a += p.res[o];
         add[r] = a;
       }
+      if (!direct && p.slab_cn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (nok && co < p.Cout) outp[(long)co * p.Npos + n] = acc[tm][tn][r];
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -204,10 +215,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Conv2Params p) {
   }
 }
 
-// out = sum_z slab[z] + bias + residual   (the deterministic split-K combine)
+// out = sum_z slab[z] + bias + residual   (the deterministic split-K combine).  slab_cn: the slabs are [co][n] (see
+// Conv2Params) and are walked in that order -- contiguous reads of every slab, one scattered write.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nsplit,
                                      const float* __restrict__ bias, const float* __restrict__ res,
-                                     float* __restrict__ out, long total, int Cout, int HW) {
+                                     float* __restrict__ out, long total, int Cout, int HW, long Npos, int slab_cn) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float v = slabs[i];
     int z = 1;
@@ -217,9 +229,19 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
       v = (((v + a) + b) + c) + d;
     }
     for (; z < nsplit; ++z) v += slabs[z * slab_stride + i];
-    if (bias) v += bias[(i / HW) % Cout];
-    if (res) v += res[i];
-    out[i] = v;
+    long o = i;
+    int co;
+    if (slab_cn) {
+      co = (int)(i / Npos);
+      const long n = i - (long)co * Npos;
+      const long b = n / HW;
+      o = (b * Cout + co) * HW + (n - b * HW);
+    } else {
+      co = (int)((i / HW) % Cout);
+    }
+    if (bias) v += bias[co];
+    if (res) v += res[o];
+    out[o] = v;
   }
 }
 
@@ -435,6 +457,7 @@ extern "C" int i2r_conv2d_fwd_packed_f32(const float* x, const float* wp, const 
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Cout4 = Cout4; p.HW = H * W; p.Kpad = Kpad;
   p.Npos = Npos; p.chunks_per_split = pl.chunks_per_split; p.nsplit = pl.nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_CONV_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* cn = getenv("I2R_CONV_SLAB_CN"); p.slab_cn = (pl.nsplit > 1 && H * W < 32 && !(cn && cn[0] == '0')) ? 1 : 0; }
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(i2r_cdiv(Npos, pl.bn), i2r_cdiv(Cout, pl.bm), pl.nsplit);
   switch (pl.variant) {
@@ -450,7 +473,7 @@ extern "C" int i2r_conv2d_fwd_packed_f32(const float* x, const float* wp, const 
     int nb = i2r_cdiv(total, 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, splitk_ws, p.slab_stride, pl.nsplit, bias,
-                       residual, out, total, Cout, H * W);
+                       residual, out, total, Cout, H * W, Npos, p.slab_cn);
   }
   return i2r_check_launch("conv2d_fwd");
 }
