@@ -70,3 +70,35 @@ def test_c_abi_rejects_what_the_kernel_does_not_cover():
         _lib.call("i2r_attention_bwd_h2", p(x), p(x), p(x), p(x), p(x), p(x), p(x), 1, 1, 32, None)
     with pytest.raises(_lib.I2RError):
         _lib.call("i2r_attention_bwd_h2", p(x), p(x), p(x), p(x), p(x), p(x), None, 1, 1, 128, None)
+
+
+def test_values_beyond_fp16_range_never_give_a_finite_wrong_gradient():
+    """The range contract of the f16x2 kernels: v of magnitude 3e4 drives dS' = P (dP' - delta') 2^-10 past
+    65504.  Every gradient element is then either non-finite -- which the optimiser's skip and
+    GraphedTrainStep.check_range act on -- or right; none is finite and wrong."""
+    from imageni2r_amd import ops
+    B, heads, T = 2, 2, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qkv = torch.randn(B, 3 * 64 * heads, T, device="cuda", generator=g)
+    qkv.view(B * heads, 64, 3, T)[:, :, 2] *= 3.0e4
+    da = torch.randn(B, 64 * heads, T, device="cuda", generator=g)
+    ref = _reference(qkv, da, heads)
+    a, lse = ops.attention_fwd(qkv, heads, save_lse=True)
+    got = ops.attention_bwd(qkv, a, lse, da, heads)
+    assert not torch.isfinite(got).all(), "this input is meant to leave fp16's range"
+    fin = torch.isfinite(got)
+    scale = ref.abs().reshape(B * heads, 64, 3, T).amax(dim=(0, 1, 3)).repeat(B * heads, 64, 1).unsqueeze(-1)
+    err = ((got.double() - ref).abs().reshape(B * heads, 64, 3, T) / scale)[fin.reshape(B * heads, 64, 3, T)]
+    assert err.numel() == 0 or float(err.max()) < 1e-3
+    # and the exact kernels (forward and backward: what check_range falls back to) take the same input in their stride
+    prev = ops._TRAIN_FWD_H2[0]
+    ops.set_train_fwd_h2("0")
+    try:
+        a32, lse32 = ops.attention_fwd(qkv, heads, save_lse=True)
+        exact = ops.attention_bwd(qkv, a32, lse32, da, heads)
+    finally:
+        ops.set_train_fwd_h2(prev)
+    assert torch.isfinite(exact).all()
+    e5, r5 = exact.reshape(B * heads, 64, 3, T), ref.reshape(B * heads, 64, 3, T)
+    for sel in range(3):
+        assert _err(e5[:, :, sel], r5[:, :, sel]) < TOL
