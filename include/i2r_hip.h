@@ -91,7 +91,7 @@ int i2r_conv2d_pack_weight_h2_dgrad(const float* w /* OIHW */, void* wp, int Cou
 /* Both split-f16 packs for many layers in ONE launch (the training step packs every layer's weights once per step).
  * table: device int64 rows {w, wp, Cout, Cin, ksize, dgrad} -- wp as for i2r_conv2d_pack_weight_h2 (dgrad 0) or
  * i2r_conv2d_pack_weight_h2_dgrad (dgrad 1); blockmap: device int32 pairs {row, block}, a row needing
- * ceil(pairs / i2r_conv2d_pack_h2_block_pairs()) blocks, pairs = i2r_conv2d_packed_h2_bytes(...) / 4. */
+ * ceil(pairs / block_pairs) blocks: block_pairs from the query below, pairs = a quarter of the layout's packed_h2_bytes. */
 int i2r_conv2d_pack_h2_block_pairs(void);
 int i2r_conv2d_pack_h2_multi(const void* table, const void* blockmap, int nblocks, i2r_stream_t stream);
 int i2r_conv2d_dgrad_h2(const float* dy, const void* wpd, float* dx, const float* scale, float* splitk_ws,
