@@ -165,6 +165,84 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(GnP p) {
   }
 }
 
+// Forward for SMALL groups (n <= 4 * LPG: one float4 per lane) when a launch has many of them (the 4x4 / 2x2 levels at
+// inference batches): every LPG-lane slot walks GPS groups with all GPS loads issued before the first reduction -- the
+// one-group form keeps 16 bytes per lane in flight and streamed these levels at 2.8-3.3 TB/s.
+template <int LPG, int GPS>
+__global__ __launch_bounds__(256) void gn_fwd_small_kernel(GnP p) {
+  const int sl = threadIdx.x % LPG;
+  const long slot = (long)blockIdx.x * (256 / LPG) + threadIdx.x / LPG;
+  const int cpg = p.C / p.G, n = cpg * p.HW;
+  const long ngroups = (long)p.B * p.G;
+  const bool lane_in = sl * 4 < n;
+  const int cl = (sl * 4) >> p.sh, hw = (sl * 4) & (p.HW - 1);  // this lane's channel within the group, pixel
+  float4 v[GPS];
+  bool valid[GPS];
+  int bb[GPS], gg[GPS];
+#pragma unroll
+  for (int gi = 0; gi < GPS; ++gi) {
+    const long wg = slot * GPS + gi;
+    valid[gi] = wg < ngroups;
+    bb[gi] = valid[gi] ? (int)(wg / p.G) : 0;
+    gg[gi] = valid[gi] ? (int)(wg % p.G) : 0;
+    const int c = gg[gi] * cpg + cl;
+    const float* q;
+    if (p.x2)
+      q = c < p.C1 ? p.x + ((long)bb[gi] * p.C1 + c) * p.HW + hw
+                   : p.x2 + ((long)bb[gi] * (p.C - p.C1) + (c - p.C1)) * p.HW + hw;
+    else
+      q = p.x + ((long)bb[gi] * p.C + c) * p.HW + hw;
+    v[gi] = (valid[gi] && lane_in) ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const uint64_t off = eff_offset(p.offset, p.rng_step);
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+  for (int gi = 0; gi < GPS; ++gi) {
+    const float s = (v[gi].x + v[gi].y) + (v[gi].z + v[gi].w);
+    const float mean = seg_sum<LPG>(s) / (float)n;
+    float q = 0.0f;
+    if (lane_in) {
+      float d0 = v[gi].x - mean, d1 = v[gi].y - mean, d2 = v[gi].z - mean, d3 = v[gi].w - mean;
+      q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float rstd = 1.0f / sqrtf(seg_sum<LPG>(q) / (float)n + p.eps);
+    if (!valid[gi]) continue;
+    const long wg = slot * GPS + gi;
+    if (sl == 0 && p.mean_out) {
+      p.mean_out[wg] = mean;
+      p.rstd_out[wg] = rstd;
+    }
+    if (!lane_in) continue;
+    const int c = gg[gi] * cpg + cl;
+    const float gm = p.gamma[c], bt = p.beta[c];
+    float u[4] = {(v[gi].x - mean) * rstd * gm + bt, (v[gi].y - mean) * rstd * gm + bt,
+                  (v[gi].z - mean) * rstd * gm + bt, (v[gi].w - mean) * rstd * gm + bt};
+    if (p.ss) {
+      const float* ssp = p.ss + (long)(p.ss_batch == 1 ? 0 : bb[gi]) * 2 * p.C;
+      float sc = ssp[c] + 1.0f, shf = ssp[p.C + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = u[j] * sc + shf;
+    }
+    if (p.act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = silu_fast(u[j]);
+    }
+    const long base = ((long)bb[gi] * p.C + (long)gg[gi] * cpg) * p.HW;
+    if (p.drop_p > 0.0f) {
+      uint4 r = keep_bits(p.seed, off, base / 4 + sl);
+      u[0] *= keep_of(r.x, p.drop_p, inv_keep);
+      u[1] *= keep_of(r.y, p.drop_p, inv_keep);
+      u[2] *= keep_of(r.z, p.drop_p, inv_keep);
+      u[3] *= keep_of(r.w, p.drop_p, inv_keep);
+    }
+    if (p.split_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = split_pack(u[j]);
+    }
+    reinterpret_cast<float4*>(p.y + base)[sl] = make_float4(u[0], u[1], u[2], u[3]);
+  }
+}
+
 // Backward, same ownership.  Per-channel sums (dgamma/dbeta partials, dscale/dshift) are reductions over runs of
 // min(LPG, HW/4) lanes, accumulated over the HW/(4*LPG) register slots a channel spans when HW > 4*LPG.
 template <int LPG, int NV>
@@ -472,6 +550,12 @@ static void gn_launch(const GnP& p, hipStream_t s) {
       hipLaunchKernelGGL(groupnorm_bwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
     else
       hipLaunchKernelGGL(groupnorm_fwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
+  } else if (!BWD && n <= 128 && groups >= 16384 && !(getenv("I2R_GN_SMALL") && getenv("I2R_GN_SMALL")[0] == '0')) {
+    // many small groups: four groups per lane slot, their loads in flight together
+    if (n <= 64)
+      hipLaunchKernelGGL((gn_fwd_small_kernel<16, 4>), dim3(i2r_cdiv(groups, 4 * 16)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((gn_fwd_small_kernel<32, 4>), dim3(i2r_cdiv(groups, 4 * 8)), dim3(256), 0, s, p);
   } else if (n <= 64) {
     GN_GO(16, 1);
   } else if (n <= 128) {
