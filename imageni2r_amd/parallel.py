@@ -61,10 +61,16 @@ class GradBucketReducer:
     (one 1-element all-reduce, no host sync; or pass ``n_total`` when the caller knows it -- no collective at all):
     each bucket is then scaled by n_r / N before it is summed and ``finish()`` does not divide.  The weighting stays in
     force until ``set_local_count(None)``.
+
+    ``host_stage=True`` is the REHEARSAL form for boxes with fewer GPUs than ranks (ranks share a device, the group is
+    gloo): every bucket crosses to a host tensor, is summed there and copied back in ``finish()`` -- the same hooks,
+    counters and call sequence as on RCCL, no device tensor is ever handed to gloo.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
+                 host_stage: bool = False):
         self.group = group
+        self.host_stage = bool(host_stage)
         self._weight = None      # device scalar n_local / N_total, or None = equal batches (plain mean)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -74,6 +80,7 @@ class GradBucketReducer:
         self._arrived: List[int] = []
         self._work: List[Optional[object]] = []
         self.defer = False       # True: hooks only adopt/count; collectives start at launch_all() (graph-replayed backward)
+        self._next = 0           # first bucket the hooks have not started yet (buckets start in index order)
         cur: List[torch.nn.Parameter] = []
         cur_bytes = 0
 
@@ -131,7 +138,10 @@ class GradBucketReducer:
         flat = self.buckets[b]
         if self._weight is not None:
             flat.mul_(self._weight)
-        if self.world > 1:
+        if self.world > 1 and self.host_stage:
+            host = flat.cpu()  # (synchronises the stream: rehearsal only)
+            self._work[b] = (dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True), host)
+        elif self.world > 1:
             self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._work[b] = True  # started (world 1: the weighting alone)
@@ -143,8 +153,15 @@ class GradBucketReducer:
             view.copy_(p.grad)      # first step / after zero_grad(set_to_none=True): adopt the bucket storage
             p.grad = view
         self._arrived[b] += 1
-        if self._arrived[b] == self._need[b] and not self.defer and (self.world > 1 or self._weight is not None):
-            self._start(b)
+        if not self.defer and (self.world > 1 or self._weight is not None):
+            # Buckets start strictly in index order on every rank, whatever order their gradients arrive in: a
+            # bucket that completes early (a layer's weight before an earlier bucket's last bias) waits for its
+            # predecessors.  launch_all() / finish() use the same order, so a rank whose backward was a replayed
+            # graph pairs with a rank whose backward fired these hooks.
+            while self._next < len(self.buckets) and self._arrived[self._next] >= self._need[self._next]:
+                if self._work[self._next] is None:
+                    self._start(self._next)
+                self._next += 1
 
     def launch_all(self):
         """Start every bucket's all-reduce now (used when backward ran inside a replayed HIP graph, where the hooks
@@ -161,12 +178,28 @@ class GradBucketReducer:
             if self.world > 1 or self._weight is not None:
                 if self._work[b] is None:
                     self._start(b)
-                if self._work[b] is not True:
+                if isinstance(self._work[b], tuple):   # host-staged rehearsal: sum arrived on the host, copy it back
+                    work, host = self._work[b]
+                    work.wait()
+                    flat.copy_(host)
+                elif self._work[b] is not True:
                     self._work[b].wait()
                 if self._weight is None:
                     flat.div_(self.world)  # equal batches: plain mean; weighted: the n_r / N factors already sum to 1
             self._work[b] = None
             self._arrived[b] = 0
+        self._next = 0
+
+    def reset(self):
+        """Forget the arrivals the hooks counted WITHOUT any collective: for backwards whose gradients are thrown away
+        on this rank alone (the warm-up steps before a graph capture -- another rank may not be capturing at all, so a
+        collective here would pair with one of its real steps).  Must not be called with a collective in flight."""
+        for b in range(len(self.buckets)):
+            if self._work[b] is not None and self._work[b] is not True:
+                raise RuntimeError("GradBucketReducer.reset: a bucket's all-reduce is in flight; call finish()")
+            self._work[b] = None
+            self._arrived[b] = 0
+        self._next = 0
 
     def zero_grad(self):
         """Zero the buckets in place (keeps the views bound; cheaper than set_to_none + re-adoption)."""

@@ -14,7 +14,10 @@ The only thing left out is the reference's per-step ``loss.item()`` host sync (o
 device scalar; call ``.item()`` when you log.
 
 Data parallel: with a `GradBucketReducer` the capture is split after backward -- graph 1 (forward + backward), the
-bucketed RCCL all-reduce launched eagerly, graph 2 (optimiser tail) -- no collective is captured.
+bucketed RCCL all-reduce launched eagerly, graph 2 (optimiser tail) -- no collective is captured, and none is ISSUED
+while capturing either (the warm-up steps run rank-local): every rank issues exactly one round of bucket all-reduces per
+call, whether that call captures, replays or runs eagerly, so ranks that first meet a new input shape on different
+steps (a short last batch on one rank only) stay paired.
 """
 from __future__ import annotations
 
@@ -56,18 +59,29 @@ class GraphedTrainStep:
             ops.set_slots_zeroed(False)
         return loss.detach()
 
-    def _eager(self, x_tilde_img, mask):
+    def _eager(self, x_tilde_img, mask, local_only=False):
+        """One uncaptured step.  ``local_only``: no collective at all (the throw-away warm-up steps of a capture --
+        ranks capture when THEY first see a shape, so a collective here could pair with another rank's real step)."""
         if self.opt._table_key is None:
             self.opt.prepare()  # gradient slots exist from the FIRST step on: eager and replayed steps run the same kernels
         prev = ops.rng_step()
         ops.set_rng_step(self.rng_counter)
+        red = self.reducer
+        was_deferred = red.defer if red is not None else False
         try:
+            if red is not None and local_only:
+                red.defer = True   # hooks adopt and count, nothing is launched
             loss = self._fwd_bwd(x_tilde_img, mask)
-            if self.reducer is not None:
-                self.reducer.finish()
+            if red is not None:
+                if local_only:
+                    red.reset()
+                else:
+                    red.finish()
             self.opt.step()
         finally:
             ops.set_rng_step(prev)
+            if red is not None:
+                red.defer = was_deferred
         return loss
 
     def _generation(self):
@@ -100,7 +114,7 @@ class GraphedTrainStep:
             saved = [t.clone() for t in live]
             with torch.enable_grad():
                 for _ in range(2):
-                    self._eager(static_x, static_m)
+                    self._eager(static_x, static_m, local_only=True)  # rank-local: gradients are not averaged
             torch._foreach_copy_(live, saved)
             del saved
             if getattr(self.model, "use_ema", False):
@@ -127,7 +141,7 @@ class GraphedTrainStep:
             ops.set_rng_step(prev)
             if self.reducer is not None:
                 self.reducer.defer = False
-                self.reducer.finish()  # reset the arrival counters the capture-time hooks advanced
+                self.reducer.reset()  # the arrivals the capture-time hooks counted; NO collective (see _eager)
         entry = (g1, g2, static_x, static_m, loss, self._generation())
         self._entries[tuple(static_x.shape)] = entry
         return entry

@@ -76,6 +76,19 @@ def recovery_loss(x_tilde, x_ts):
     return torch.sqrt(torch.nn.functional.mse_loss(x_tilde[obs], x_ts[obs])) * 10
 
 
+def propagate_values(x_ts):
+    """run_irregular.py:25-39 / :213 -- a series with EVERY entry missing is replaced, in place and in batch order, by
+    its successor in the batch (the last one by its predecessor).  Without it such a series has an all-False padding
+    mask: every key of the completion stage's attention is masked, its rows come out NaN, and the recovery loss and
+    the completion weights with them.  Same result as the reference's per-sample loop -- a row is only ever replaced
+    at its own turn, so looking the all-missing rows up once is the same thing -- for one host sync instead of one
+    per sample."""
+    B = x_ts.shape[0]
+    for b in torch.isnan(x_ts).reshape(B, -1).all(dim=1).nonzero().flatten().tolist():
+        x_ts[b] = x_ts[b + 1 if b + 1 < B else b - 1]
+    return x_ts
+
+
 class TrainIteration:
     """One iteration of run_irregular.py:209-244 for a diffusion model on the HIP path and a completion stage that stays
     on PyTorch-ROCm (``completion(x_ts, padding_masks) -> x_recon``; the reference's embedder + decoder composed, or any
@@ -83,19 +96,28 @@ class TrainIteration:
 
     ``diffusion_step``: ``GraphedTrainStep`` (replayed HIP graph incl. clip + AdamW + EMA), or None for the eager
     sequence with ``diffusion_optimizer`` exactly as :220-230.  Returns ``(diffusion loss, recovery loss)`` as device
-    scalars -- no host sync inside."""
+    scalars.  ``x_ts`` is the loader's batch without its time-index column (:211); like the reference's loop body the
+    call starts with `propagate_values` on it (:213, in place; its one host sync is the only one in here --
+    ``propagate=False`` for callers that already did it).
+
+    ``reuse_completion`` changes how much dropout RNG the completion stage consumes (one forward instead of two), so
+    with its dropout live the trajectory is a different, equally distributed one; ``reuse_completion=False`` keeps the
+    reference's two forwards."""
 
     def __init__(self, model, completion, completion_optimizer, diffusion_step=None, diffusion_optimizer=None,
-                 reuse_completion=True, empty_cache=False):
+                 reuse_completion=True, empty_cache=False, propagate=True):
         if (diffusion_step is None) == (diffusion_optimizer is None):
             raise ValueError("give either a GraphedTrainStep or the diffusion optimiser of the eager loop")
         self.model, self.completion, self.opt_er = model, completion, completion_optimizer
         self.step, self.opt = diffusion_step, diffusion_optimizer
         self.reuse_completion = reuse_completion
         self.empty_cache = empty_cache
+        self.propagate = propagate
 
     def __call__(self, x_ts):
         m = self.model
+        if self.propagate:
+            x_ts = propagate_values(x_ts)                                    # :213
         padding_masks = ~torch.isnan(x_ts).any(dim=-1)                       # :214
         x_img, mask = m.ts_to_img_with_mask(x_ts)                            # :215-216, one kernel
         x_recon = self.completion(x_ts, padding_masks)                       # :217-218

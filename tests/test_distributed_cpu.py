@@ -212,6 +212,87 @@ def test_unequal_batches_slot_path_and_rank_rng_world2():
     assert res[0]["seed"] == torch.initial_seed() & ((1 << 63) - 1)  # rank 0 keeps the single-process streams
 
 
+def _worker_asym_capture(rank, world, port, q):
+    """What GraphedTrainStep does when only ONE rank meets a new input shape (a short last batch on that rank alone):
+    that rank runs two throw-away warm-up steps (`_eager(local_only=True)`: hooks deferred, `reset()` instead of
+    `finish()`) and a capture pass before its real step; the other rank goes straight to its real step.  Both must
+    issue the same collectives -- a warm-up that all-reduced would pair with the other rank's REAL buckets."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        torch.manual_seed(0)
+        x = torch.randn(8, 6)
+        y = torch.randn(8, 3)
+        b, e = shard_range(8, rank, world)
+        m = _SlotNet()
+        red = GradBucketReducer(m.parameters(), bucket_bytes=300)
+        calls = []
+        orig_start = red._start
+        red._start = lambda bi: (calls.append(bi), orig_start(bi))[1]
+        out = {}
+        for step in range(2):
+            capturing = rank == step  # rank 0 "captures" at step 0, rank 1 at step 1
+            if capturing:
+                for _ in range(2):    # warm-up: rank-local, other data, gradients discarded
+                    red.zero_grad()
+                    red.defer = True
+                    ((m(x[b:e] * 3.0 + 1.0) - y[b:e]) ** 2).mean().backward()
+                    red.reset()
+                    red.defer = False
+                red.zero_grad()       # the capture pass itself: hooks deferred, counters reset, nothing launched
+                red.defer = True
+                ((m(x[b:e]) - y[b:e]) ** 2).mean().backward()
+                red.defer = False
+                red.reset()
+                assert not calls, "a capture must not issue a collective"
+                red.launch_all()      # the replay that follows the capture
+            else:
+                red.zero_grad()
+                ((m(x[b:e]) - y[b:e]) ** 2).mean().backward()
+            red.finish()
+            out[step] = ([p.grad.clone().numpy() for p in m.parameters()], len(calls))
+            calls.clear()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_on_one_rank_only_issues_no_extra_collective_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_asym_capture, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    x = torch.randn(8, 6)
+    y = torch.randn(8, 3)
+    m = _SlotNet()
+    ((m(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in m.parameters()]
+    for rank in range(world):
+        for step in range(2):
+            grads, ncalls = res[rank][step]
+            assert ncalls == res[1 - rank][step][1] > 0, (rank, step)  # same number of collectives on both ranks
+            for g, r in zip(grads, ref):
+                assert torch.allclose(torch.from_numpy(g), r, rtol=1e-5, atol=1e-7), (rank, step)
+
+
+def test_reducer_reset_refuses_with_a_collective_in_flight():
+    m = _model()
+    red = GradBucketReducer(m.parameters())
+    red._work[0] = object()
+    with pytest.raises(RuntimeError):
+        red.reset()
+
+
 def test_gradient_accumulation_over_two_backwards_sums_in_the_slot():
     """A second backward without zero_grad: the parameter already holds a gradient, so the kernels must not write the
     slot again (autograd would add the alias to itself and double the LAST gradient)."""

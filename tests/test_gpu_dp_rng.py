@@ -70,6 +70,29 @@ def test_graphed_step_with_reducer_world1_matches_plain_graph():
         assert e_rms < 1e-3 and e_max < 2e-2, (e_max, e_rms)
 
 
+def test_every_call_issues_one_round_of_bucket_reductions_capturing_or_not():
+    """Ranks capture when THEY first meet an input shape (a short last batch on one rank only), so a capture must
+    issue exactly what a replay issues: one start per bucket, in bucket order -- no collective from the warm-up steps
+    or from resetting the arrival counters (those would pair with another rank's real step)."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep
+    from imageni2r_amd.parallel import GradBucketReducer
+    m = _model()
+    red = GradBucketReducer(m.net.parameters(), bucket_bytes=1 << 20)
+    opt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    step = GraphedTrainStep(m, opt, reducer=red)
+    red.set_local_count(4, n_total=4)   # weighting on: at world size 1 a bucket "start" is then a real kernel launch
+    started = []
+    orig = red._start
+    red._start = lambda b: (started.append(b), orig(b))[1]
+    sizes = [4, 4, 2, 4, 2]             # captures at calls 0 (batch 4) and 2 (batch 2), replays otherwise
+    for x, k in _batches(m, len(sizes), sizes):
+        started.clear()
+        assert np.isfinite(step(x, k).item())
+        assert started == list(range(len(red.buckets))), (tuple(x.shape), started)
+    assert len(step._entries) == 2
+    assert int(m.model_ema.num_updates.item()) == len(sizes)
+
+
 def test_one_update_per_batch_and_one_graph_per_shape():
     """The reference's loaders have no drop_last (utils/utils_data.py:243): the short last batch of an epoch and the
     first full batch after it must each cost ONE optimiser step, and each shape is captured once."""

@@ -4,7 +4,7 @@ full-size network on the HIP path, against vectors captured from the REFERENCE i
 
 Bars: delay embedding / mask / img_to_ts bit-exact; denoiser output, loss, every parameter gradient and the sampled
 series within 1e-4 (BASELINE.json north_star), in both inference conv maths (f16x2-split MFMA and exact fp32 MFMA)
-and both training-forward modes.  Three error measures are asserted side by side: max|a-b|/max|b| (`rel_err`),
+and both training-forward modes; the optional reduced-precision inference path ("f16") within its own 1e-2 bar.  Three error measures are asserted side by side: max|a-b|/max|b| (`rel_err`),
 the RMS-relative error, and the worst single channel's max/max (`chan_rel_err`)."""
 import json
 import os
@@ -48,7 +48,12 @@ def case(request):
     torch.cuda.empty_cache()
 
 
-@pytest.fixture(params=["f16x2", "f32"])
+# "f16" is north_star's optional reduced-precision path (the 3x3 convs multiply the f16 high halves only):
+# its bar is 1e-2, on every shape of this file
+MATH_TOL = {"f16x2": TOL, "f32": TOL, "f16": 1e-2}
+
+
+@pytest.fixture(params=["f16x2", "f32", "f16"])
 def conv_math(request):
     import imageni2r_amd
     from imageni2r_amd import ops
@@ -99,10 +104,11 @@ def test_denoiser(case, conv_math):
     name, m, args, S, d, g = case
     with torch.no_grad():
         D = m.net(cu(d["x"]), cu(d["sigma"]))
-        check(D.cpu().numpy(), g[name + "/D_per_sample"], (name, conv_math, "per-sample sigma"))
+        check(D.cpu().numpy(), g[name + "/D_per_sample"], (name, conv_math, "per-sample sigma"), MATH_TOL[conv_math])
         D2 = m.net(cu(d["x"][:1]).double(), torch.tensor(1.7, dtype=torch.float64))
         assert D2.dtype == torch.float32
-        check(D2.cpu().numpy(), g[name + "/D_scalar_sigma"], (name, conv_math, "0-dim fp64 sigma"))
+        check(D2.cpu().numpy(), g[name + "/D_scalar_sigma"], (name, conv_math, "0-dim fp64 sigma"),
+              MATH_TOL[conv_math])
 
 
 def test_loss_and_every_parameter_gradient(case, train_fwd):
@@ -145,7 +151,8 @@ def test_sampled_series(case, conv_math, use_graph):
     proc = DiffusionProcess(args, m.net, (args.input_channels, S, S), use_graph=use_graph)
     out = proc.sampling(sampling_number=1, xT=d["xT"])
     assert out.dtype == torch.float64 and tuple(out.shape) == (1, args.input_channels, S, S)
-    check(out.cpu().numpy(), g[name + "/sample"], (name, conv_math, "graph" if use_graph else "eager"))
+    check(out.cpu().numpy(), g[name + "/sample"], (name, conv_math, "graph" if use_graph else "eager"),
+          MATH_TOL[conv_math])
     if use_graph:
         assert torch.equal(out, proc.sampling(sampling_number=1, xT=d["xT"]))
 

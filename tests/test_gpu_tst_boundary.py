@@ -110,3 +110,37 @@ def test_boundary_iteration_trains_both_stages_like_the_reference_loop_body():
     for a, b in zip(ca, cb):
         assert rel_err(b.numpy(), a.numpy()) < 1e-4
     assert la[0][1] > la[-1][1]                               # and the completion stage is actually learning
+
+
+def test_all_missing_series_is_replaced_like_the_reference_loop_does():
+    """run_irregular.py:213 (propagate_values): a series with every entry missing would give the completion stage an
+    all-masked attention row -> NaN recovery loss -> NaN weights.  The boundary iteration applies the reference's
+    replacement rule first; losses and weights stay finite."""
+    from imageni2r_amd import FusedAdamW, GraphedTrainStep
+    from imageni2r_amd.tst_boundary import CompletionStandIn, TrainIteration, propagate_values
+    # the rule itself, against the reference's sequential loop restated on the host
+    g = torch.Generator().manual_seed(4)
+    for holes in ([1], [3], [0, 1], [2, 3], [0, 1, 2, 3], []):
+        x = torch.rand(4, 24, 3, generator=g)
+        x[1, 5, :] = float("nan")
+        for b in holes:
+            x[b] = float("nan")
+        want = x.clone()
+        for b in range(4):
+            if torch.isnan(want[b]).all():
+                want[b] = want[b + 1] if b + 1 < 4 else want[b - 1]
+        got = propagate_values(x.clone().to(DEV)).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0))
+    m = _model()
+    torch.manual_seed(1)
+    comp = CompletionStandIn(3, 24, dropout=0.0).to(DEV).train()
+    opt_er = torch.optim.Adam(comp.parameters())
+    fopt = FusedAdamW(m.net.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, ema=(m.model_ema, m.net))
+    it = TrainIteration(m, comp, opt_er, diffusion_step=GraphedTrainStep(m, fopt))
+    x_ts = _batch(seed=6)
+    x_ts[2] = float("nan")
+    for _ in range(3):
+        loss, loss_e = it(x_ts.clone())
+        assert np.isfinite(float(loss)) and np.isfinite(float(loss_e))
+    assert all(bool(torch.isfinite(p).all()) for p in comp.parameters())
+    assert all(bool(torch.isfinite(p).all()) for p in m.net.parameters())
