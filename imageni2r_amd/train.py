@@ -28,13 +28,17 @@ from .optim import FusedAdamW
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer: FusedAdamW, reducer=None, use_graph=True):
+    def __init__(self, model, optimizer: FusedAdamW, reducer=None, use_graph=True, apply_update=True):
+        """``apply_update=False`` leaves the optimiser tail (clip + AdamW + EMA) out: the call is then
+        run_irregular.py:215-227 only -- gradients are left in the parameters' slots for the caller (gradient
+        accumulation, a foreign optimiser, the "forward + backward only" measurement of bench.py)."""
         if not isinstance(optimizer, FusedAdamW):
             raise TypeError("GraphedTrainStep needs a FusedAdamW optimiser (device-resident step state)")
         self.model = model
         self.opt = optimizer
         self.reducer = reducer
         self.use_graph = use_graph
+        self.apply_update = bool(apply_update)
         self.range_check_every = 64   # calls between looks at the optimiser's skipped-step count (one host sync each)
         self._calls = 0
         self._skipped_seen = 0
@@ -77,7 +81,8 @@ class GraphedTrainStep:
                     red.reset()
                 else:
                     red.finish()
-            self.opt.step()
+            if self.apply_update:
+                self.opt.step()
         finally:
             ops.set_rng_step(prev)
             if red is not None:
@@ -129,10 +134,10 @@ class GraphedTrainStep:
             with torch.cuda.graph(g1):
                 ops.new_pack_epoch()  # weights are packed inside the graph: replays read the live weights
                 loss = self._fwd_bwd(static_x, static_m)
-                if self.reducer is None:
+                if self.reducer is None and self.apply_update:
                     self.opt.step()
             g2 = None
-            if self.reducer is not None:
+            if self.reducer is not None and self.apply_update:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=g1.pool()):
                     self.opt.step()
@@ -193,8 +198,9 @@ class GraphedTrainStep:
         static_x.copy_(x_tilde_img)
         static_m.copy_(mask)
         g1.replay()
-        if g2 is not None:
+        if self.reducer is not None:
             self.reducer.launch_all()
             self.reducer.finish()
+        if g2 is not None:
             g2.replay()
         return loss
