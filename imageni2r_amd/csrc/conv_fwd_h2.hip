@@ -562,8 +562,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 //     (the kernel above: 16 loads, 48 permutes, 32 DPP moves + 32 selects).  Image rows of 16 need no border select at
 //     all (the row shift's zero fill IS the border); rows of 32 take the neighbouring column tile's edge lane through a
 //     row rotate as the shift's fill value.
-// Taken for W in {4, 8, 16, 32}, Cin % 32 == 0, Cout > 64, no split-K, >= 512 tiles of 256 positions x 128 channels
-// (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 0 = rows of 4 / 8, 1 = 16, 2 = 32.
+// Taken for W in {2, 4, 8, 16, 32}, Cin % 32 == 0, Cout > 64, >= 256 tiles of 256 positions x 128 channels, never
+// split-K (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 0 = rows of 4 / 8, 1 = 16, 2 = 32.
 #ifndef M16_ABL
 #define M16_ABL 0  /* tuning builds only (tools/r3_m16_ablate.sh): 1 no fragment reads from LDS, 2 no fragment build,
                       4 no weight staging, 8 no global loads in the loop, 16 no barrier -- results are then garbage */
@@ -592,15 +592,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;   // XCD-aware tile order (see conv_fwd_h2_kernel)
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  // PERSISTENT: one workgroup per CU walks its tiles (a workgroup of this size costs ~5 us to launch -- 6 % of a
+  // 256-channel tile -- and a resident one lets the epilogue's stores drain under the next tile's first loads).
+  // XCD-aware order as in conv_fwd_h2_kernel: the 32 workgroups of an XCD (ids 8 apart) take 32 consecutive entries
+  // of that XCD's tile list (output-channel tile fastest), so the Cout tiles of a position tile run side by side on
+  // one L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  for (int q = slot;; q += nslots) {
   const int mt = q % p.mtiles;
   const long nt = (long)(q / p.mtiles) * 8 + xcd;
   const int m0 = mt * BM;
   const long n0 = nt * BN;
-  if (n0 >= p.Npos) return;
-
-  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  if (n0 >= p.Npos) break;   // (position tiles grow with q: every later entry is past the end too; workgroup-uniform)
 
   // ---- weight pieces: a row's 24 pieces = 2 packed 16-channel chunks x (hi | lo) x 3 taps x 2 channel octets, fetched
   // in the packed layout's own order (192 contiguous bytes per chunk and row)
@@ -789,13 +794,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     load_group(0, 0, 0);
     if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
     for (int c = 0; c < c_end; ++c) {
+      if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks its partner's staging (+1-2 %)
 #pragma unroll
       for (int g = 0; g < 6; ++g) {
+        // the next group's 8 fragment reads go out ONE per three MFMAs: issued as a block they hold the wave's
+        // instruction stream for ~50 cycles in which no MFMA issues and the matrix pipe runs dry (measured: 12 %)
         if (g < 5) load_group((g + 1) & 1, g + 1, c);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_group(g & 1, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
       if (c + 1 == c_end) {       // last chunk: group 0 meets group 1's last staging barrier, group 1 just leaves
         if (!grp) __syncthreads();
         break;
@@ -814,8 +827,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   }
 
   // Epilogue.  Group 0 gets here one phase before group 1 and transposes through LDS while group 1 still reads the
-  // weight stage of the last chunk: the patches live in the OTHER stage (its last readers passed a barrier since).
-  float* patches = reinterpret_cast<float*>(smem + (c_end & 1) * ABUF) + wave * (32 * EPI_PITCH);
+  // weight stage of the last chunk, and a fast wave is in the next tile's prologue while a slow one still transposes:
+  // the patches have an LDS area of their own behind the two stages.
+  float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
   auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 16 ct + n16
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -825,6 +839,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
         for (int i = 0; i < 4; ++i) sc[(tt * 16 + 4 * kg + i) * EPI_PITCH + ct * 16 + n16] = acc[2 * T + tt][ct][i];
   };
   h2_epilogue_quad_put<4, true>(p, put, p.out, true, n0 + wave * 32, m0, lane, patches, p.ablate, omul);
+  // Next tile: group 0 fills stage 0 while group 1 may still be in its last MFMA phase, which reads the stage of the
+  // last chunk -- stage 1 for an even chunk count; an odd one (Cin = 96, 160, ...) needs the groups to meet first.
+  if (c_end & 1) __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1263,10 +1281,17 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.mtiles = i2r_cdiv(Cout, bm);
   // the large 3x3 layers: the 16x16x32 MFMA form (conv3x3_h2_m16_kernel)
   const char* m16 = getenv("I2R_H2_M16");  // (read per call: A/B probes and tests flip it inside one process)
-  if (ksize == 3 && !(m16 && atoi(m16) == 0) && !one_term && !x2 && bm == 128 && Cout > 64 && bn == 256 &&
-      nsplit == 1 && Cin % 32 == 0 && (W == 4 || W == 8 || W == 16 || W == 32) && !getenv("I2R_H2_NODPP")) {
-    const int lds = 2 * 2 * 128 * (96 * 2);
-    dim3 grid((i2r_cdiv(Npos, 256) + 7) / 8 * 8 * p.mtiles);
+  static const long m16_mintiles = getenv("I2R_H2_M16_MINTILES") ? atol(getenv("I2R_H2_M16_MINTILES")) : 256;
+  const bool m16_size = (bn == 256 && nsplit == 1) ||
+                        (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= m16_mintiles;
+  if (ksize == 3 && !(m16 && atoi(m16) == 0) && !one_term && !x2 && bm == 128 && Cout > 64 && m16_size &&
+      Cin % 32 == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || (W == 2 && H == 2 && !up_in && !up_res)) &&
+      !getenv("I2R_H2_NODPP")) {
+    const int lds = 2 * 2 * 128 * (96 * 2) + 8 * 32 * EPI_PITCH * 4;
+    const long per_xcd = (long)((i2r_cdiv(Npos, 256) + 7) / 8) * p.mtiles;  // tile-list entries of one XCD
+    dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));                // one workgroup per CU
+    p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
+    p.nsplit = 1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
 #define H2_M16(SP_, WM_)                                                                                        \

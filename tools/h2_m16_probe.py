@@ -55,7 +55,11 @@ CASES = [(512, 128, 128, 16, True, True, False, False),
          (1024, 256, 256, 8, True, True, True, True),
          (128, 256, 256, 32, True, True, True, True),
          (512, 128, 256, 16, False, True, False, False),    # fp32 input split in the kernel (training forwards)
-         (512, 512, 256, 16, True, False, False, False)]
+         (512, 512, 256, 16, True, False, False, False),
+         (8192, 512, 512, 2, True, True, False, False),     # 2x2 images: eight image rows per 16-lane row
+         (8200, 1024, 512, 2, True, False, False, False),
+         (2048, 256, 256, 4, True, True, False, False),     # exactly 256 tiles: one workgroup per CU
+         (2050, 512, 256, 4, True, False, True, False)]
 worst = 0.0
 for (B, Cin, Cout, H, split, has_res, up_in, up_res) in CASES:
     gen = torch.Generator().manual_seed(B + Cin + Cout + H)
