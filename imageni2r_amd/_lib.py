@@ -76,6 +76,7 @@ SIGNATURES = {
     "i2r_opt_chunk_elems": [],
     "i2r_fused_adamw_ema_step": [P, P, I, P, P, P, P, F, F, F, F, F, F, F, I, P],
     "i2r_heun_init_f64": [P, P, L, D, P],
+    "i2r_heun_init_f64_from_f64": [P, P, L, D, P],
     "i2r_heun_euler_f64": [P, P, P, P, L, D, D, P],
     "i2r_heun_correct_f64": [P, P, P, P, P, L, D, D, P],
 }

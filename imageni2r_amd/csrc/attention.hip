@@ -1014,11 +1014,8 @@ extern "C" int i2r_attention_bwd_h2(const float* qkv, const float* out, const fl
 #define BWD_GO(QW_)                                                                                                 \
   do {                                                                                                              \
     auto kern = attn_bwd_dkv_h2_kernel<QW_>;                                                                        \
-    static bool attr = false;                                                                                       \
-    if (!attr) {                                                                                                    \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE);     \
-      attr = true;                                                                                                  \
-    }                                                                                                               \
+    static bool attr[64] = {false}; \
+    if (!i2r_lds_attr((const void*)kern, 2 * DKV_STAGE, attr)) return I2R_ERR_HIP; \
     hipLaunchKernelGGL(kern, dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 2 * DKV_STAGE, s, qkv, lse, delta_ws, \
                        dout, scale, dqkv, heads, T);                                                                \
     hipLaunchKernelGGL(attn_bwd_dq_h2_kernel<QW_>, dim3(T / (32 * QW_), B * heads), dim3(64 * QW_), 0, s, qkv, lse, \

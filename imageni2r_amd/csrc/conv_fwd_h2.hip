@@ -1257,12 +1257,8 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
 #define H2_PERSIST(SP_)                                                                                       \
   do {                                                                                                        \
     auto kern = conv1x1_h2_persist_kernel<SP_>;                                                               \
-    static bool attr = false;                                                                                 \
-    if (!attr) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                \
-                                2 * 2 * 128 * (64 * 2 + 16) + 8 * 32 * EPI_PITCH * 4);                        \
-      attr = true;                                                                                            \
-    }                                                                                                         \
+    static bool attr[64] = {false}; \
+    if (!i2r_lds_attr((const void*)kern, 2 * 2 * 128 * (64 * 2 + 16) + 8 * 32 * EPI_PITCH * 4, attr)) return I2R_ERR_HIP; \
     for (int tile0 = 0; tile0 < all_tiles; tile0 += 1024) {                                                   \
       const int ntiles = tile0 + 1024 < all_tiles ? tile0 + 1024 : all_tiles;                                 \
       const int rounds = i2r_cdiv(ntiles - tile0, cap);                                                       \
@@ -1292,18 +1288,11 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
     dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));                // one workgroup per CU
     p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
     p.nsplit = 1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
 #define H2_M16(SP_, WM_)                                                                                        \
   do {                                                                                                          \
     auto kern = conv3x3_h2_m16_kernel<SP_, WM_>;                                                                \
     static bool attr[64] = {false};                                                                             \
-    if (!attr[dev]) {                                                                                           \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   \
-      I2R_REQUIRE(e == hipSuccess, "conv2d_fwd_h2: cannot raise the dynamic LDS limit to %d bytes: %s", lds,    \
-                  hipGetErrorString(e));                                                                        \
-      attr[dev] = true;                                                                                         \
-    }                                                                                                           \
+    if (!i2r_lds_attr((const void*)kern, lds, attr)) return I2R_ERR_HIP;                                        \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);                                                       \
   } while (0)
 #define H2_M16_W(SP_)                                  \
@@ -1327,12 +1316,8 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
 #define H2_LAUNCH(KS_, SP_, NW_, DP_, TM_, BM_)                                                                    \
   do {                                                                                                             \
     auto kern = conv_fwd_h2_kernel<KS_, SP_, NW_, DP_, TM_, BM_>;                                                  \
-    static bool attr = false;                                                                                      \
-    if (!attr) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
-                                KS_ == 3 ? 4 * 128 * (48 * 2 + 16) : lds1);                                        \
-      attr = true;                                                                                                 \
-    }                                                                                                              \
+    static bool attr[64] = {false}; \
+    if (!i2r_lds_attr((const void*)kern, KS_ == 3 ? 4 * 128 * (48 * 2 + 16) : lds1, attr)) return I2R_ERR_HIP; \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), KS_ == 3 ? lds3 : lds1, s, p);                                  \
   } while (0)
 #define H2_PICK_NW(KS_, SP_, DP_, TM_, BM_)            \

@@ -387,17 +387,13 @@ static void wgrad_tile_plan(const WgradParams& p, int& chunks_per_split, int& ns
   nsplit = (int)((total + chunks_per_split - 1) / chunks_per_split);
 }
 
-static void wgrad_tile_launch(const WgradParams& p, hipStream_t s) {
+static bool wgrad_tile_launch(const WgradParams& p, hipStream_t s) {
   dim3 grid(i2r_cdiv(p.Cin, 32), i2r_cdiv(p.Cout, 32), p.nsplit);
 #define WG_TILE(W_)                                                                                          \
   do {                                                                                                       \
     auto kern = conv_wgrad3_tile_kernel<W_>;                                                                 \
-    static bool attr = false;                                                                                \
-    if (!attr) {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                WgTile<W_>::LDS_BYTES);                                                      \
-      attr = true;                                                                                           \
-    }                                                                                                        \
+    static bool attr[64] = {false}; \
+    if (!i2r_lds_attr((const void*)kern, WgTile<W_>::LDS_BYTES, attr)) return false; \
     hipLaunchKernelGGL(kern, grid, dim3(256), WgTile<W_>::LDS_BYTES, s, p);                                  \
   } while (0)
   if (p.W == 8)
@@ -407,6 +403,7 @@ static void wgrad_tile_launch(const WgradParams& p, hipStream_t s) {
   else
     WG_TILE(32);
 #undef WG_TILE
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1, vector loader
@@ -663,10 +660,11 @@ extern "C" int i2r_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
       if (p.db) (void)hipMemsetAsync(p.db, 0, sizeof(float) * (size_t)p.Cout, s);
       p.atomic = 1;
     }
-    if (t3)
-      wgrad_tile_launch(p, s);
-    else
+    if (t3) {
+      if (!wgrad_tile_launch(p, s)) return I2R_ERR_HIP;
+    } else {
       wgrad_tile1_launch(p, s);
+    }
     return i2r_check_launch("conv2d_wgrad");
   }
   if (Cout <= 32)
@@ -739,10 +737,11 @@ extern "C" int i2r_conv2d_wgrad_det_f32(const float* x, const float* dy, float* 
     p.db = dbias ? ws : nullptr;
     p.atomic = 0;
     p.slab_stride = n_dw + p.Cout;
-    if (t3)
-      wgrad_tile_launch(p, s);
-    else
+    if (t3) {
+      if (!wgrad_tile_launch(p, s)) return I2R_ERR_HIP;
+    } else {
       wgrad_tile1_launch(p, s);
+    }
     int nb = i2r_cdiv(n_all, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, s, ws, p.slab_stride, p.nsplit, dw, dbias,

@@ -215,6 +215,9 @@ extern "C" int i2r_masked_edm_loss(const float* D, const float* x, const float* 
 __global__ void heun_init_kernel(const float* __restrict__ latents, double* __restrict__ x, long n, double t0) {
   GRID_STRIDE(i, n) x[i] = (double)latents[i] * t0;
 }
+__global__ void heun_init_d_kernel(const double* __restrict__ latents, double* __restrict__ x, long n, double t0) {
+  GRID_STRIDE(i, n) x[i] = latents[i] * t0;
+}
 // d_cur = (x_hat - D) / t_hat;  x_next = x_hat + (t_next - t_hat) * d_cur
 __global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float* __restrict__ D,
                                   double* __restrict__ d_cur, double* __restrict__ x_next, long n, double t_hat,
@@ -241,6 +244,11 @@ __global__ void heun_correct_kernel(const double* __restrict__ x_hat, const doub
 extern "C" int i2r_heun_init_f64(const float* latents, double* x, long n, double t0, i2r_stream_t stream) {
   I2R_REQUIRE(latents && x && n > 0, "heun_init: bad argument");
   hipLaunchKernelGGL(heun_init_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, latents, x, n, t0);
+  return i2r_check_launch("heun_init");
+}
+extern "C" int i2r_heun_init_f64_from_f64(const double* latents, double* x, long n, double t0, i2r_stream_t stream) {
+  I2R_REQUIRE(latents && x && n > 0, "heun_init: bad argument");
+  hipLaunchKernelGGL(heun_init_d_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, latents, x, n, t0);
   return i2r_check_launch("heun_init");
 }
 extern "C" int i2r_heun_euler_f64(const double* x_hat, const float* D, double* d_cur, double* x_next, long n,

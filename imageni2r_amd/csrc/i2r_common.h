@@ -23,6 +23,23 @@ int i2r_check_launch(const char* what);
 
 static inline int i2r_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Raises a kernel's dynamic-LDS limit once per (kernel, DEVICE): the attribute belongs to the device's copy of the
+// code object, so a process that launches on a second GPU has to set it there too.  `done`: the call site's static
+// per-device flags.  False (and the error text set) when the runtime refuses.
+static inline bool i2r_lds_attr(const void* kern, int bytes, bool (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return true;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    i2r_set_error("cannot raise the dynamic LDS limit of a kernel to %d bytes on device %d: %s", bytes, dev,
+                  hipGetErrorString(e));
+    return false;
+  }
+  done[dev] = true;
+  return true;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -85,23 +85,29 @@ class TS2img_Karras(nn.Module):
                           RuntimeWarning, stacklevel=2)
             ops.set_train_fwd_h2("0")
             ops.new_pack_epoch()
-            output, weight = self.forward_irregular(x, mask)
+            output, weight = self.forward_irregular(x, mask, _reuse_offset=True)  # the SAME sigma / noise draw
             loss = ops.MaskedLossFn.apply(output, x.detach(), mask, weight.reshape(-1).contiguous())
             value = loss.detach().item()
         to_log['karras loss'] = value
         return loss, to_log
 
-    def forward_irregular(self, x, mask, labels=None, augment_pipe=None):
+    def forward_irregular(self, x, mask, labels=None, augment_pipe=None, _reuse_offset=False):
         """sigma ~ exp(N(P_mean, P_std)); noise only on observed pixels; returns (D(x + n*mask, sigma), weight)
-        (our.py:70-78)."""
+        (our.py:70-78).  ``_reuse_offset``: draw from the Philox offset of the previous call again (the fp32
+        recomputation of a step whose f16x2 forward overflowed must see the same sigma and noise)."""
         if augment_pipe is not None or labels is not None:
             raise NotImplementedError("augment_pipe / labels are never passed by ImagenI2R")
         rnd, noise = self._injected if self._injected is not None else (None, None)
         seed = ops.rng_seed()
         step = ops.rng_step()
+        if step is not None:
+            offset = 0
+        elif _reuse_offset and getattr(self, "_last_noise_offset", None) is not None:
+            offset = self._last_noise_offset
+        else:
+            offset = self._last_noise_offset = next(_noise_counter)
         xn, sigma, weight = ops.edm_noise(x.detach().contiguous(), mask, self.P_mean, self.P_std, self.sigma_data,
-                                          rnd=rnd, noise=noise, seed=seed,
-                                          offset=0 if step is not None else next(_noise_counter), step=step)
+                                          rnd=rnd, noise=noise, seed=seed, offset=offset, step=step)
         D_yn = self.net(xn, sigma)
         return D_yn, weight.reshape(-1, 1, 1, 1)
 

@@ -499,8 +499,10 @@ class DhariwalUNet(torch.nn.Module):
         if plan is None:
             # plans are a few KB of launch tables; captured graphs hold raw pointers into them, so none is ever
             # dropped while the network lives (keys: batch rows x parameter/slot addresses -- a handful)
+            # (a long-lived serving process that has met 256 distinct batch sizes: later ones take the per-block Linear
+            # path -- slower, never fatal; no cached plan may be dropped, graphs replay against them)
             if len(plans) >= 256:
-                raise ops._lib.I2RError("affine_all: too many distinct (batch, parameter address) plans")
+                return None
             plan = plans[key] = ops.AffinePlan(lins, emb.shape[0])
         flat = [t for l in lins for t in (l.weight, l.bias)]
         outs = ops.AffineAllFn.apply(emb, plan, *flat)

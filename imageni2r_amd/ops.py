@@ -769,9 +769,13 @@ def masked_edm_loss(D, x, mask, weight, want_grad=True):
 
 
 def heun_init(latents, t0):
-    _chk(latents, "latents")
+    """x_0 = latents.double() * t_0 (sampler.py:45); fp64 latents are multiplied unrounded."""
+    if latents.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"heun_init: expected float32/float64 latents, got {latents.dtype}")
+    _chk(latents, "latents", latents.dtype)
     x = torch.empty(latents.shape, dtype=torch.float64, device=latents.device)
-    _lib.call("i2r_heun_init_f64", _p(latents), _p(x), latents.numel(), float(t0), _stream())
+    fn = "i2r_heun_init_f64_from_f64" if latents.dtype == torch.float64 else "i2r_heun_init_f64"
+    _lib.call(fn, _p(latents), _p(x), latents.numel(), float(t0), _stream())
     return x
 
 

@@ -191,6 +191,11 @@ class FusedAdamW(torch.optim.Optimizer):
         ``max_grad_norm`` is set).  Nothing -- weights, moments, step count, EMA -- is touched by a skipped step."""
         return 0 if self.scalars is None else int(self.scalars[6].item())
 
+    def last_step_skipped(self):
+        """Device scalar, 1.0 if the last step was skipped for a non-finite gradient norm (no host sync: read it
+        together with the loss when logging -- ``bool(opt.last_step_skipped())`` syncs)."""
+        return self.scalars[7]
+
     def grad_norm(self):
         """Total gradient norm measured by the last step (device scalar, as clip_grad_norm_ would have returned)."""
         return self.scalars[0]

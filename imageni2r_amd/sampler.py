@@ -109,14 +109,17 @@ class DiffusionProcess:
 
     def _graph_key(self, latents):
         # the kernel-selection switches are part of the key: a graph replays the kernels it was captured with
-        return (tuple(latents.shape), latents.device.index,
+        return (tuple(latents.shape), latents.dtype, latents.device.index,
                 hash(tuple(p.data_ptr() for p in self.net.parameters())), ops.kernel_mode_key())
 
     @torch.no_grad()
     def sample(self, latents, class_labels=None):
         if self.S_churn != 0:
             raise NotImplementedError("S_churn != 0 is never used by ImagenI2R (sampler.py:26)")
-        latents = latents.to(device=self.device, dtype=torch.float32).contiguous()
+        # fp32 latents (what sampling() draws) or fp64 ones, kept as they are: the reference multiplies
+        # latents.to(float64) by t_0 (:45), so a caller's fp64 xT must reach the state unrounded
+        keep = latents.dtype if latents.dtype in (torch.float32, torch.float64) else torch.float32
+        latents = latents.to(device=self.device, dtype=keep).contiguous()
         if not latents.is_cuda:
             raise ops._lib.I2RError("DiffusionProcess: device must be a HIP ('cuda') device; no CPU fallback")
         t_steps = self._t_steps()

@@ -40,6 +40,7 @@ class GraphedTrainStep:
         self.use_graph = use_graph
         self.apply_update = bool(apply_update)
         self.range_check_every = 64   # calls between looks at the optimiser's skipped-step count (one host sync each)
+        self.max_skipped_exact = 8    # skipped steps per look tolerated once the forward is already exact fp32
         self._calls = 0
         self._skipped_seen = 0
         self._entries = {}  # input shape -> captured step (the short last batch of an epoch gets its own, once)
@@ -170,10 +171,22 @@ class GraphedTrainStep:
                 ops.new_pack_epoch()
                 self._entries.clear()
             else:
+                # nothing left to fall back to: the reference would have written NaN into every weight at the first
+                # such batch (clip_grad_norm_ + AdamW, run_irregular.py:228-229); here the updates were skipped
+                if new > self.max_skipped_exact:
+                    raise FloatingPointError(
+                        f"GraphedTrainStep: {new} of the last {self.range_check_every} steps had a non-finite "
+                        "gradient norm although the forward runs on the exact fp32 kernels: the loss itself is not "
+                        "finite (NaN / inf in the data?).  The updates of those steps were skipped.")
                 warnings.warn(f"GraphedTrainStep: {new} step(s) had a non-finite gradient norm and were skipped "
                               "(the forward is already exact fp32: the loss itself is not finite)",
                               RuntimeWarning, stacklevel=2)
         return new
+
+    def last_step_skipped(self):
+        """Device scalar (1.0 = the optimiser skipped the last step: non-finite gradient norm); read it with the
+        loss when logging -- no extra sync is made here."""
+        return self.opt.last_step_skipped()
 
     def __call__(self, x_tilde_img, mask):
         """One full train step; returns the loss as a 0-dim device tensor (valid until the next call)."""

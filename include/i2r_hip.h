@@ -108,7 +108,9 @@ int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* 
  * variant); shapes that need no split-K use no scratch at all.  The function calls no hipMalloc / hipFree or any
  * allocating routine.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
  * threads) race; serialise them.  Nothing in the array has to be cleared between calls.  Make the FIRST call on each
- * device outside stream capture (it looks the array's device address up once per device). */
+ * device outside stream capture (it looks the array's device address up once per device).  The array used is the one
+ * of the CURRENT device (hipGetDevice): call with the device that owns x / out / the stream current, as for every
+ * other entry point of this library. */
 long i2r_conv2d_fwd_h2_noalloc_max_floats(void);
 int i2r_conv2d_fwd_h2_noalloc(const float* x, const void* wp, const float* bias, const float* residual, float* out,
                               int B, int Cin, int H, int W, int Cout, int ksize, int x_is_split, i2r_stream_t stream);
@@ -239,6 +241,9 @@ int i2r_masked_edm_loss(const float* D, const float* x, const float* mask, const
 
 /* ---- Heun sampler updates: models/sampler.py:45, :56-57, :62-63 (fp64 state, fp32 denoiser output) ------------------ */
 int i2r_heun_init_f64(const float* latents, double* x, long n, double t0, i2r_stream_t stream);
+/* the same for latents the caller hands over in fp64: :45 is `latents.to(torch.float64) * t_steps[0]`, so fp64 latents
+ * enter the state unrounded */
+int i2r_heun_init_f64_from_f64(const double* latents, double* x, long n, double t0, i2r_stream_t stream);
 int i2r_heun_euler_f64(const double* x_hat, const float* D, double* d_cur, double* x_next, long n, double t_hat,
                        double t_next, i2r_stream_t stream);
 int i2r_heun_correct_f64(const double* x_hat, const double* x_next, const float* Dp, const double* d_cur,

@@ -477,6 +477,26 @@ def test_sampler_golden(tiny_gpu):
     assert_close(ts.cpu().numpy(), ref_ts, TOL)
 
 
+def test_sampler_fp64_latents_enter_the_state_unrounded(tiny_gpu):
+    """models/sampler.py:45 is `latents.to(torch.float64) * t_steps[0]`: latents handed over in fp64 are not rounded to
+    fp32 on the way in (sampling(N) itself draws fp32, so only a caller's own xT can be fp64)."""
+    from imageni2r_amd import DiffusionProcess, ops as _ops
+    gen = torch.Generator().manual_seed(31)
+    xT = torch.randn(2, 3, 8, 8, generator=gen, dtype=torch.float64)
+    x0 = _ops.heun_init(xT.to(DEV), 80.0)
+    assert torch.equal(x0.cpu(), xT * 80.0) and not torch.equal(x0.cpu(), xT.float().double() * 80.0)
+    args = tiny_args(device=DEV)
+    sd = {k: v.detach().cpu() for k, v in tiny_gpu.net.state_dict().items()}
+    a = tiny_args()
+    spec = O.unet_spec(a.img_resolution, a.input_channels, a.unet_channels, a.ch_mult, a.attn_resolution)
+    with torch.no_grad():
+        ref = O.heun_sample(lambda xx, s: O.edm_precond(sd, spec, xx, s), xT)
+    for use_graph in (False, True):
+        out = DiffusionProcess(args, tiny_gpu.net, (3, 8, 8), use_graph=use_graph).sample(xT)
+        assert out.dtype == torch.float64
+        assert_close(out.cpu().numpy(), ref.numpy(), TOL, use_graph)
+
+
 def test_sampler_two_concurrent_half_batch_graphs(tiny_gpu):
     """Large batches are sampled as two half-batch graphs replayed side by side on two streams: same series as one
     graph over the whole batch (per-series arithmetic does not depend on the batch), and stable across replays."""
