@@ -410,26 +410,54 @@ extern "C" int i2r_pos_embedding_f32(const float* x, float* out, int B, int num_
 // ------------------------------------------------------------------ power-of-two scale of a tensor (f16x2 dgrad)
 // scale_out = {s, 1/s} with s = 2^(13 - floor(log2 max|x|)): s * x peaks in [2^13, 2^14) -- inside fp16's range with a
 // factor 4 to spare, and everything down to 2^-27 of the peak stays representable.  max|x| = 0, inf or NaN: s = 1 (a
-// non-finite gradient then reaches the optimiser as such and its step is skipped).  `scratch`: one uint32 that is 0 on
-// entry and is left 0 (the bit pattern of a non-negative float orders like the float).
-// 16-byte loads; one atomic per WORKGROUP, and only when it can still raise the maximum (a plain look first): with
-// one atomicMax per wave on the same word the 4096 waves of a 17 MB tensor queued at the L2 for 50 us -- ten times
-// what reading the tensor takes.
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long n,
-                                                          unsigned* __restrict__ scratch) {
+// non-finite gradient then reaches the optimiser as such and its step is skipped).  `scratch`: two uint32 (running
+// maximum, arrival count) that are 0 on entry and are left 0 (the bit pattern of a non-negative float orders like the
+// float).  16-byte loads; one atomic per WORKGROUP: with one atomicMax per wave on the same word the 4096 waves of a
+// 17 MB tensor queued at the L2 for 50 us -- ten times what reading the tensor takes.
+__device__ __forceinline__ void pow2_scale_of(unsigned m, float* __restrict__ scale_out) {
+  int e = (int)(m >> 23) - 127;              // floor(log2 max|x|) for normal numbers
+  float s = 1.0f;
+  if (m != 0 && m < 0x7F800000u) {           // finite, non-zero
+    int k = 13 - e;
+    if (k > 100) k = 100;                    // (subnormal or tiny peaks: keep 2^k and 2^-k both normal)
+    if (k < -100) k = -100;
+    s = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+  }
+  scale_out[0] = s;
+  scale_out[1] = 1.0f / s;
+}
+// ONE launch: every workgroup folds its slice's max |x| bits into scratch[0] (memory-side atomic), then takes a ticket
+// on scratch[1]; the last to arrive reads the final maximum, writes {s, 1/s} and leaves both words zero again.  The
+// grid is bounded (<= ABSMAX_MAX_WG workgroups) because the tickets serialise memory-side at ~0.2 per ns: with one
+// ticket per 256 threads of a 1024-workgroup grid the tickets alone took longer than the separate one-thread kernel
+// they replace (round 2); at <= 128 of them they cost well under a microsecond.
+#define ABSMAX_MAX_WG 128
+__global__ __launch_bounds__(256) void absmax_pow2_kernel(const float* __restrict__ x, long n,
+                                                          unsigned* __restrict__ scratch,
+                                                          float* __restrict__ scale_out) {
   __shared__ unsigned red[4];
   unsigned m = 0;
   const long n4 = (((uintptr_t)x) & 15) == 0 ? (n >> 2) : 0;
   const uint4* x4 = reinterpret_cast<const uint4*>(x);
   const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (long i = t0; i < n4; i += stride) {
-    const uint4 v = x4[i];
-    const unsigned a = v.x & 0x7FFFFFFFu, b = v.y & 0x7FFFFFFFu, c = v.z & 0x7FFFFFFFu, d = v.w & 0x7FFFFFFFu;
-    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
-    m = q > m ? q : m;
+  long i = t0;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four 16-byte loads in flight per thread
+    const uint4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+#define ABSMAX4(v)                                                                                                 \
+    {                                                                                                               \
+      const unsigned qa = v.x & 0x7FFFFFFFu, qb = v.y & 0x7FFFFFFFu, qc = v.z & 0x7FFFFFFFu, qd = v.w & 0x7FFFFFFFu; \
+      const unsigned ab = qa > qb ? qa : qb, cd = qc > qd ? qc : qd, q = ab > cd ? ab : cd;                         \
+      m = q > m ? q : m;                                                                                            \
+    }
+    ABSMAX4(v0) ABSMAX4(v1) ABSMAX4(v2) ABSMAX4(v3)
   }
-  for (long i = 4 * n4 + t0; i < n; i += stride) {
-    const unsigned b = __builtin_bit_cast(unsigned, x[i]) & 0x7FFFFFFFu;
+  for (; i < n4; i += stride) {
+    const uint4 v = x4[i];
+    ABSMAX4(v)
+  }
+#undef ABSMAX4
+  for (long j = 4 * n4 + t0; j < n; j += stride) {
+    const unsigned b = __builtin_bit_cast(unsigned, x[j]) & 0x7FFFFFFFu;
     m = b > m ? b : m;
   }
 #pragma unroll
@@ -442,30 +470,24 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
   if (threadIdx.x == 0) {
     const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
     m = a > b ? a : b;
-    if (m != 0 && m > *reinterpret_cast<volatile unsigned*>(scratch)) atomicMax(scratch, m);
+    if (m != 0) atomicMax(scratch, m);
+    __threadfence();                                   // the maximum is out before the ticket is
+    const unsigned ticket = atomicAdd(scratch + 1, 1u);
+    if (ticket == gridDim.x - 1) {                     // every other workgroup's maximum has landed
+      __threadfence();
+      const unsigned final_m = atomicExch(scratch, 0u);  // read memory-side, and leave the word zero
+      atomicExch(scratch + 1, 0u);
+      pow2_scale_of(final_m, scale_out);
+    }
   }
-}
-__global__ void pow2_scale_kernel(unsigned* __restrict__ scratch, float* __restrict__ scale_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned m = scratch[0];
-  scratch[0] = 0;
-  int e = (int)(m >> 23) - 127;              // floor(log2 max|x|) for normal numbers
-  float s = 1.0f;
-  if (m != 0 && m < 0x7F800000u) {           // finite, non-zero
-    int k = 13 - e;
-    if (k > 100) k = 100;                    // (subnormal or tiny peaks: keep 2^k and 2^-k both normal)
-    if (k < -100) k = -100;
-    s = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
-  }
-  scale_out[0] = s;
-  scale_out[1] = 1.0f / s;
 }
 extern "C" int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* scale_out,
                                          i2r_stream_t stream) {
   I2R_REQUIRE(x && scratch && scale_out && n > 0, "absmax_pow2_scale: bad argument");
-  int nb = ew_grid((n + 3) / 4);
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
-  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, scale_out);
+  long nb = (n / 4 + 256 * 8 - 1) / (256 * 8);  // >= 8 16-byte loads per thread before another workgroup is worth it
+  if (nb < 1) nb = 1;
+  if (nb > ABSMAX_MAX_WG) nb = ABSMAX_MAX_WG;
+  hipLaunchKernelGGL(absmax_pow2_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch,
+                     scale_out);
   return i2r_check_launch("absmax_pow2_scale");
 }

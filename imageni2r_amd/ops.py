@@ -366,13 +366,13 @@ _SCALE_SCRATCH = {}
 
 
 def _scale_scratch(device):
-    """One zeroed uint32 per device for i2r_absmax_pow2_scale_f32 (the kernel leaves it zero).  Made outside any
+    """Two zeroed uint32 per device for i2r_absmax_pow2_scale_f32 (the kernel leaves them zero).  Made outside any
     stream capture: the first data-gradient call of a process is always an eager one (graph warm-up)."""
     t = _SCALE_SCRATCH.get(device)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.I2RError("conv2d_dgrad_h2: first use inside a stream capture; run one eager step first")
-        t = _SCALE_SCRATCH[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        t = _SCALE_SCRATCH[device] = torch.zeros(2, dtype=torch.int32, device=device)
     return t
 
 

@@ -97,7 +97,8 @@ int i2r_conv2d_pack_h2_multi(const void* table, const void* blockmap, int nblock
 int i2r_conv2d_dgrad_h2(const float* dy, const void* wpd, float* dx, const float* scale, float* splitk_ws,
                         long splitk_floats, int B, int Cin, int H, int W, int Cout, int ksize, i2r_stream_t stream);
 /* scale_out[0] = s = 2^(13 - floor(log2 max|x|)), scale_out[1] = 1/s (s = 1 when max|x| is 0 or not finite).
- * scratch: one uint32, zero on entry, left zero.  (No counterpart in the reference: it serves the kernel above.) */
+ * scratch: TWO uint32 (running maximum, arrival count), zero on entry, left zero: one launch -- the last workgroup to
+ * arrive writes the pair.  (No counterpart in the reference: it serves the kernel above.) */
 int i2r_absmax_pow2_scale_f32(const float* x, long n, unsigned* scratch, float* scale_out, i2r_stream_t stream);
 /* i2r_conv2d_fwd_h2 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that may
  * not call hipMalloc or hand over a workspace -- code under HIP graph capture, tight serving loops, harnesses that
