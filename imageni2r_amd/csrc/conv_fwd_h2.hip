@@ -555,15 +555,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 //   * a k-step is 32 input channels at one tap, a chunk = (kernel row r, 32-channel block): 3 k-steps, 144 MFMAs per
 //     wave and barrier.  The weight stage is filled from TWO consecutive 16-channel chunks of the packed layout (a
 //     fragment's 8 consecutive k are 8 consecutive channels of one of them), so no second weight layout exists.
-//   * lane = (position n16 = lane & 15, channel group kg = lane >> 4): a wave's 32 positions are two 16-lane column
-//     tiles (positions +0 and +16), its 128 channels eight 16-row tiles; accumulators acc[8][2] of 4 floats.
-//   * the centre tap is converted to hi / lo fragments ONCE; the left / right taps are DPP ROW shifts of the packed
-//     fragment registers (two channels per register): per 32 channels and lane 16 loads, 16 permutes and 32 DPP moves
-//     (the kernel above: 16 loads, 48 permutes, 32 DPP moves + 32 selects).  Image rows of 16 need no border select at
-//     all (the row shift's zero fill IS the border); rows of 32 take the neighbouring column tile's edge lane through a
-//     row rotate as the shift's fill value.
+//   * lane = (position pair n16 = lane & 15, channel group kg = lane >> 4): lane n16 owns positions 2 n16 and
+//     2 n16 + 1 of the wave's 32; column tile 0 = the even, column tile 1 = the odd positions.  One 8-byte load per
+//     channel brings both (for an input upsampled on the fly one dword IS both); its 128 channels are eight 16-row
+//     tiles; accumulators acc[8][2] of 4 floats.
+//   * the centre tap is converted to hi / lo fragments ONCE; the left tap of an odd position and the right tap of an
+//     even one are the OTHER column tile's centre fragment as it stands, the remaining two are DPP ROW shifts of the
+//     packed fragment registers (two channels per register): per 32 channels and lane 8 loads, 16 permutes and 16 DPP
+//     moves (the kernel above: 16 loads, 48 permutes, 32 DPP moves + 32 selects; one position per lane and tile in
+//     this kernel: 16 loads, 32 DPP moves -- the pair form measured +3 to +10 % on every probe shape).  Image rows of
+//     32 need no border select at all (the row shift's zero fill IS the border); narrower rows mask two taps.
 // Taken for W in {2, 4, 8, 16, 32}, Cin % 32 == 0, Cout > 64, >= 256 tiles of 256 positions x 128 channels, never
-// split-K (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 0 = rows of 4 / 8, 1 = 16, 2 = 32.
+// split-K (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 2 = image rows of 32, 0 = narrower ones.
 #ifndef M16_ABL
 #define M16_ABL 0  /* tuning builds only (tools/r3_m16_ablate.sh): 1 no fragment reads from LDS, 2 no fragment build,
                       4 no weight staging, 8 no global loads in the loop, 16 no barrier -- results are then garbage */
@@ -577,7 +580,7 @@ __device__ __forceinline__ unsigned row_dpp(unsigned fill, unsigned v) {
 #define DPP_ROW_ROR1 0x121  /* lane i <- lane (i-1) mod 16 */
 #define DPP_ROW_ROR15 0x12F /* lane i <- lane (i+1) mod 16 */
 
-template <bool SPLIT, int WM>
+template <bool SPLIT, int WM, bool UP>
 __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   constexpr int BM = 128, NT = 512, BN = 256;
   constexpr int KC = 96;                // halves per weight row and stage half: 3 taps x 32 channels
@@ -622,35 +625,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   }
   const unsigned stepA = (unsigned)p.Cout * 384;  // bytes of packed weights per 32-channel chunk
 
-  // ---- positions: column tile ct holds position n0 + 32 wave + 16 ct + n16
-  bool nvalid[2], has_left[2], has_right[2];
-  int pb[2], py[2], px[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const long nj = n0 + wave * 32 + ct * 16 + n16;
-    nvalid[ct] = nj < p.Npos;
-    pb[ct] = py[ct] = px[ct] = 0;
-    if (nvalid[ct]) {
-      pb[ct] = (int)(nj / p.HW);
-      const int pos = (int)(nj % p.HW);
-      py[ct] = pos / p.W;
-      px[ct] = pos % p.W;
-    }
-    has_left[ct] = px[ct] > 0;
-    has_right[ct] = px[ct] < p.W - 1;
+  // ---- positions: lane n16 owns the PAIR of positions n0 + 32 wave + 2 n16 + {0, 1}: column tile 0 = the even
+  // positions, column tile 1 = the odd ones.  One 8-byte load per channel fetches both (half the vector-memory
+  // instructions of one position per lane and tile), and a pixel's neighbour is mostly the OTHER column tile's value
+  // in the same lane: left of (even, lane n) = (odd, lane n-1), right of it = (odd, lane n); left of (odd, lane n) =
+  // (even, lane n), right of it = (even, lane n+1) -- two row shifts per channel pair instead of four.  W is even,
+  // so a pair never straddles an image row and both of its positions are valid or invalid together.
+  const long nj = n0 + wave * 32 + 2 * n16;
+  const bool nvalid = nj < p.Npos;
+  int pb = 0, py = 0, px = 0;
+  if (nvalid) {
+    pb = (int)(nj / p.HW);
+    const int pos = (int)(nj % p.HW);
+    py = pos / p.W;
+    px = pos % p.W;
   }
-  const int us = p.up_in;
+  const bool has_left0 = px > 0, has_right1 = px + 2 < p.W;   // (even position's left tap, odd position's right tap)
+  constexpr int us = UP ? 1 : 0;   // input upsampled x2 on the fly (compile-time: the loads differ in width)
   const unsigned chan_bytes = (unsigned)(p.HW >> (2 * us)) * 4;
-  unsigned voffB[2];
+  unsigned voffB;
   auto set_row = [&](int r) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int iy = py[ct] + r - 1;
-      const bool rok = nvalid[ct] && (unsigned)iy < (unsigned)p.H;
-      long off = ((long)pb[ct] * p.Cin + 8 * kg) * p.HW + iy * p.W + px[ct];
-      if (us) off = ((long)pb[ct] * p.Cin + 8 * kg) * (p.HW >> 2) + (iy >> 1) * (p.W >> 1) + (px[ct] >> 1);
-      voffB[ct] = rok ? (unsigned)(off * 4) : OOR;
-    }
+    const int iy = py + r - 1;
+    const bool rok = nvalid && (unsigned)iy < (unsigned)p.H;
+    long off = ((long)pb * p.Cin + 8 * kg) * p.HW + iy * p.W + px;
+    // upsampled input: both positions of the pair are source pixel (iy >> 1, px >> 1)
+    if (us) off = ((long)pb * p.Cin + 8 * kg) * (p.HW >> 2) + (iy >> 1) * (p.W >> 1) + (px >> 1);
+    voffB = rok ? (unsigned)(off * 4) : OOR;
   };
 
   f32x4 acc[8][2];
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   const int nCB32 = p.nCB >> 1;
   const int c_end = 3 * nCB32;
   uint4v ra[NA];
-  float rb[2][8];
+  float rb[2][8];   // [even | odd position][channel]
   auto load_a = [&](int c, bool live) {
     const unsigned sA = live ? (unsigned)c * stepA : OOR;
 #pragma unroll
@@ -683,8 +683,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const unsigned sB = (unsigned)(cb * 32 + j) * chan_bytes + dead;
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) rb[ct][j] = bufload(rB, voffB[ct], sB);
+      if (us) {
+        rb[0][j] = bufload(rB, voffB, sB);
+        rb[1][j] = rb[0][j];
+      } else {
+        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+        const uint2v v2 = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rB, voffB, sB, 0));
+        const unsigned u0 = v2.x, u1 = v2.y;
+        rb[0][j] = __builtin_bit_cast(float, u0);
+        rb[1][j] = __builtin_bit_cast(float, u1);
+      }
     }
   };
   float s_in = 1.0f, omul = WSCALE_INV;
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     s_in = p.in_scale[0];
     omul = WSCALE_INV * p.in_scale[1];
   }
-  // fragments [tap][column tile] of one chunk out of the raw centre-tap registers
+  // fragments [tap][column tile] of one chunk out of the raw centre-tap registers: two conversions, two row shifts
   auto build_frags = [&](half8 (*fh)[2], half8 (*fl)[2]) {
     uint4v ch[2], cl[2];
 #pragma unroll
@@ -705,38 +713,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
       ch[ct] = __builtin_bit_cast(uint4v, h8);
       cl[ct] = __builtin_bit_cast(uint4v, l8);
     }
+    uint4v lh, ll, rh, rl;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      uint4v lh, ll, rh, rl;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned vh = ch[ct][e], vl = cl[ct][e];
-        if (WM == 2 && ct == 1) {        // left of the right half-row's first pixel = the left half-row's last pixel
-          lh[e] = row_dpp<DPP_ROW_SHR1, false>(row_dpp<DPP_ROW_ROR1, false>(0u, ch[0][e]), vh);
-          ll[e] = row_dpp<DPP_ROW_SHR1, false>(row_dpp<DPP_ROW_ROR1, false>(0u, cl[0][e]), vl);
-        } else {
-          lh[e] = row_dpp<DPP_ROW_SHR1, true>(0u, vh);
-          ll[e] = row_dpp<DPP_ROW_SHR1, true>(0u, vl);
-        }
-        if (WM == 2 && ct == 0) {
-          rh[e] = row_dpp<DPP_ROW_SHL1, false>(row_dpp<DPP_ROW_ROR15, false>(0u, ch[1][e]), vh);
-          rl[e] = row_dpp<DPP_ROW_SHL1, false>(row_dpp<DPP_ROW_ROR15, false>(0u, cl[1][e]), vl);
-        } else {
-          rh[e] = row_dpp<DPP_ROW_SHL1, true>(0u, vh);
-          rl[e] = row_dpp<DPP_ROW_SHL1, true>(0u, vl);
-        }
-        if (WM == 0) {                   // several image rows inside a 16-lane row: zero the taps across their ends
-          lh[e] = has_left[ct] ? lh[e] : 0u;
-          ll[e] = has_left[ct] ? ll[e] : 0u;
-          rh[e] = has_right[ct] ? rh[e] : 0u;
-          rl[e] = has_right[ct] ? rl[e] : 0u;
-        }
+    for (int e = 0; e < 4; ++e) {
+      // left of the even position: the odd position one lane down (0 into a 16-lane row's first lane: with image rows
+      // of 32 that IS the border; narrower rows also end inside the 16 lanes)
+      lh[e] = row_dpp<DPP_ROW_SHR1, true>(0u, ch[1][e]);
+      ll[e] = row_dpp<DPP_ROW_SHR1, true>(0u, cl[1][e]);
+      rh[e] = row_dpp<DPP_ROW_SHL1, true>(0u, ch[0][e]);
+      rl[e] = row_dpp<DPP_ROW_SHL1, true>(0u, cl[0][e]);
+      if (WM != 2) {
+        lh[e] = has_left0 ? lh[e] : 0u;
+        ll[e] = has_left0 ? ll[e] : 0u;
+        rh[e] = has_right1 ? rh[e] : 0u;
+        rl[e] = has_right1 ? rl[e] : 0u;
       }
-      fh[0][ct] = __builtin_bit_cast(half8, lh);
-      fl[0][ct] = __builtin_bit_cast(half8, ll);
-      fh[2][ct] = __builtin_bit_cast(half8, rh);
-      fl[2][ct] = __builtin_bit_cast(half8, rl);
     }
+    fh[0][0] = __builtin_bit_cast(half8, lh);   // left taps:  even <- shifted odd,  odd <- even
+    fl[0][0] = __builtin_bit_cast(half8, ll);
+    fh[0][1] = fh[1][0];
+    fl[0][1] = fl[1][0];
+    fh[2][0] = fh[1][1];                         // right taps: even <- odd,          odd <- shifted even
+    fl[2][0] = fl[1][1];
+    fh[2][1] = __builtin_bit_cast(half8, rh);
+    fl[2][1] = __builtin_bit_cast(half8, rl);
   };
 
   // ---- main loop: the two waves of a SIMD ALTERNATE.  Waves 0-3 (one per SIMD) and waves 4-7 run half a period apart:
@@ -830,13 +830,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   // weight stage of the last chunk, and a fast wave is in the next tile's prologue while a slow one still transposes:
   // the patches have an LDS area of their own behind the two stages.
   float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
-  auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 16 ct + n16
+  auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 2 n16 + ct
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sc[(tt * 16 + 4 * kg + i) * EPI_PITCH + ct * 16 + n16] = acc[2 * T + tt][ct][i];
+      for (int i = 0; i < 4; ++i) {
+        // (an ext-vector store: a store through HIP's float2 STRUCT may be moved past the epilogue's float4-struct
+        // reads of the same patch by type-based alias analysis -- it was: stale patches in about half the samples)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v2 = {acc[2 * T + tt][0][i], acc[2 * T + tt][1][i]};
+        *reinterpret_cast<f32x2*>(sc + (tt * 16 + 4 * kg + i) * EPI_PITCH + 2 * n16) = v2;
+      }
   };
   h2_epilogue_quad_put<4, true>(p, put, p.out, true, n0 + wave * 32, m0, lane, patches, p.ablate, omul);
   // Next tile: group 0 fills stage 0 while group 1 may still be in its last MFMA phase, which reads the stage of the
@@ -1288,18 +1292,19 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
     dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));                // one workgroup per CU
     p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
     p.nsplit = 1;
-#define H2_M16(SP_, WM_)                                                                                        \
+#define H2_M16(SP_, WM_, UP_)                                                                                   \
   do {                                                                                                          \
-    auto kern = conv3x3_h2_m16_kernel<SP_, WM_>;                                                                \
+    auto kern = conv3x3_h2_m16_kernel<SP_, WM_, UP_>;                                                           \
     static bool attr[64] = {false};                                                                             \
     if (!i2r_lds_attr((const void*)kern, lds, attr)) return I2R_ERR_HIP;                                        \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);                                                       \
   } while (0)
 #define H2_M16_W(SP_)                                  \
   do {                                                 \
-    if (W == 16) H2_M16(SP_, 1);                       \
-    else if (W == 32) H2_M16(SP_, 2);                  \
-    else H2_M16(SP_, 0);                               \
+    if (W == 32 && up_in) H2_M16(SP_, 2, true);        \
+    else if (W == 32) H2_M16(SP_, 2, false);           \
+    else if (up_in) H2_M16(SP_, 0, true);              \
+    else H2_M16(SP_, 0, false);                        \
   } while (0)
     if (x_is_split) H2_M16_W(true);
     else H2_M16_W(false);
