@@ -170,8 +170,10 @@ template <int NQ>
 __device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, int m0, int lane, float (&bv)[NQ]) {
   const int cr = lane >> 3, lim = p.Cout - m0 - cr;
   const bool use_bias = full && p.bias != nullptr;
-  __amdgpu_buffer_rsrc_t rBias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, use_bias ? p.Cout * 4 : 0, 0x00020000);
+  // (readfirstlane: a uniform select that the compiler lowers to v_cndmask puts the descriptor into vector registers,
+  // and every load through it then becomes a waterfall loop -- seen in the 16x16x32 kernels' epilogues, 49 of them)
+  __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.bias, 0, __builtin_amdgcn_readfirstlane(use_bias ? p.Cout * 4 : 0), 0x00020000);
   const unsigned boff = (unsigned)(m0 + cr) * 4u;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) bv[q] = bufload(rBias, 8 * q < lim ? boff : OOR, (unsigned)(8 * q) * 4u);
@@ -206,9 +208,11 @@ __device__ __forceinline__ void h2_epilogue_quad_put(const ConvHParams& p, PUT p
     res_bytes = out_bytes >> 2;
     rvoff = qvalid ? (crow * hwl + (y >> 1) * ((unsigned)p.W >> 1) + (x >> 1)) * 4u : OOR;
   }
-  __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)out_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rR =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, use_res ? (int)res_bytes : 0, 0x00020000);
+  rplane = __builtin_amdgcn_readfirstlane(rplane);   // (scalar offset of every residual load: see h2_quad_bias)
+  __amdgpu_buffer_rsrc_t rO =
+      __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, __builtin_amdgcn_readfirstlane((int)out_bytes), 0x00020000);
+  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.res, 0, __builtin_amdgcn_readfirstlane(use_res ? (int)res_bytes : 0), 0x00020000);
   const int lim = p.Cout - m0 - cr;  // channel offsets below lim exist for this lane
   const int cmod = (m0 + cr) % 3;
   // every load before the first store (see the aliasing note above)
@@ -260,8 +264,14 @@ __device__ __forceinline__ void h2_epilogue_quad_put(const ConvHParams& p, PUT p
         }
         o[e] = __builtin_bit_cast(unsigned, y);
       }
-      unsigned vo = (cof < lim && (!(ablate & 1) || o[0] == 0x12345678u)) ? voff : OOR;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rO, vo, (unsigned)cof * plane, 0);
+      // The channel offset goes into the VECTOR offset, the scalar offset stays the constant 0.  A 16-byte store whose
+      // data registers are overwritten by the very next VALU instruction needs one wait state in between; the compiler
+      // inserts it only for stores WITHOUT a register in the scalar-offset field (the ISA manuals exempt those), and on
+      // gfx950 the exemption does not hold: with `cof * plane` as an SGPR offset and a v_mov into o[0] scheduled right
+      // behind the store, 16 lanes of a wave stored the NEW value of o[0] (seen in conv3x3_h2_m16_kernel's in-loop
+      // epilogue: raw accumulators of the next channel block at element 0 of a quad, timing dependent).
+      unsigned vo = (cof < lim && (!(ablate & 1) || o[0] == 0x12345678u)) ? voff + (unsigned)cof * plane : OOR;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rO, vo, 0, 0);
     }
   }
 }
@@ -593,26 +603,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   constexpr int ABUF = 2 * BM * ROWL;   // one weight stage: hi rows, then lo rows
   constexpr int NA = BM * 24 / NT;      // 16-byte weight pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index through readfirstlane: the stream counters below are advanced under `if (grp)`, and they must stay
+  // scalar for the compiler -- a counter it takes for divergent turns every buffer load into a waterfall loop)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kg = lane >> 4;
   __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-  // PERSISTENT: one workgroup per CU walks its tiles (a workgroup of this size costs ~5 us to launch -- 6 % of a
-  // 256-channel tile -- and a resident one lets the epilogue's stores drain under the next tile's first loads).
-  // XCD-aware order as in conv_fwd_h2_kernel: the 32 workgroups of an XCD (ids 8 apart) take 32 consecutive entries
-  // of that XCD's tile list (output-channel tile fastest), so the Cout tiles of a position tile run side by side on
-  // one L2.
+  // PERSISTENT, and ONE software pipeline over all the chunks of all the workgroup's tiles.  One workgroup per CU
+  // walks its tiles in the XCD-aware order of conv_fwd_h2_kernel: the 32 workgroups of an XCD (ids 8 apart) take 32
+  // consecutive entries of that XCD's tile list (output-channel tile fastest), so the Cout tiles of a position tile run
+  // side by side on one L2.  Per-shape rates of the first persistent form (a prologue, the chunk loop and an epilogue
+  // per tile) fitted time = chunks + 4.9 chunk-times per tile at a main-loop rate of 551 TF -- the MFMA-only ceiling
+  // of the ablation -- i.e. ALL of the remaining loss was per-tile: exposed load latency in the prologue and the
+  // epilogue and the two half-phases of skew between the wave groups, 29 % of a 128-channel layer's time.  Now the
+  // weight and activation load streams run ahead ACROSS tile boundaries (each stream has its own tile / chunk counter
+  // and recomputes its lane offsets when it wraps), the chunk loop never drains, and a tile boundary is just a staging
+  // phase that also holds the tile's epilogue -- beside the other group's MFMA phase.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  for (int q = slot;; q += nslots) {
-  const int mt = q % p.mtiles;
-  const long nt = (long)(q / p.mtiles) * 8 + xcd;
-  const int m0 = mt * BM;
-  const long n0 = nt * BN;
-  if (n0 >= p.Npos) break;   // (position tiles grow with q: every later entry is past the end too; workgroup-uniform)
+  const long npt = (p.Npos + BN - 1) / BN;                         // position tiles in all
+  const long lim = (npt > xcd ? (npt - xcd + 7) / 8 : 0) * p.mtiles;  // entries of this XCD's tile list
+  const int ntile = lim > slot ? (int)((lim - slot + nslots - 1) / nslots) : 0;
+  if (ntile == 0) return;   // (whole workgroup, before any barrier)
+  const int nCB32 = p.nCB >> 1;
+  const int c_end = 3 * nCB32;      // chunks per tile: (kernel row, 32-channel block)
+  const int S = ntile * c_end;      // chunks this workgroup computes
+  constexpr int us = UP ? 1 : 0;    // input upsampled x2 on the fly (compile-time: the loads differ in width)
+  const unsigned chan_bytes = (unsigned)(p.HW >> (2 * us)) * 4;
+  const unsigned stepA = (unsigned)p.Cout * 384;  // bytes of packed weights per 32-channel chunk
+  float s_in = 1.0f, omul = WSCALE_INV;
+  if (!SPLIT && p.in_scale != nullptr) {
+    s_in = p.in_scale[0];
+    omul = WSCALE_INV * p.in_scale[1];
+  }
+  auto tile_m0 = [&](int k) { return ((slot + k * nslots) % p.mtiles) * BM; };
+  auto tile_n0 = [&](int k) { return ((long)((slot + k * nslots) / p.mtiles) * 8 + xcd) * BN; };
 
-  // ---- weight pieces: a row's 24 pieces = 2 packed 16-channel chunks x (hi | lo) x 3 taps x 2 channel octets, fetched
-  // in the packed layout's own order (192 contiguous bytes per chunk and row)
-  // Waves 4-7 stage rows 0-63 of a weight tile, waves 0-3 rows 64-127 (see the main loop for why).
+  // ---- weight stream.  A row's 24 pieces = 2 packed 16-channel chunks x (hi | lo) x 3 taps x 2 channel octets,
+  // fetched in the packed layout's own order (192 contiguous bytes per chunk and row).  Waves 4-7 stage rows 0-63 of a
+  // weight tile, waves 0-3 rows 64-127 (see the main loop for why).
   unsigned voffA[NA];
   int ldsA[NA];
 #pragma unroll
@@ -620,30 +648,53 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     const int idx = (tid & 255) + 256 * j;
     const int row = (tid < 256 ? 64 : 0) + idx / 24, pq = idx % 24, kgh = pq / 12, q12 = pq % 12;
     const int hl = q12 / 6, sx = (q12 % 6) >> 1, kgl = q12 & 1;
-    voffA[j] = (m0 + row < p.Cout) ? (unsigned)((kgh * p.Cout + m0 + row) * 192 + q12 * 16) : OOR;
     ldsA[j] = (hl * BM + row) * ROWL + (sx * 4 + ((kgh * 2 + kgl) ^ ((row >> 2) & 2))) * 16;
   }
-  const unsigned stepA = (unsigned)p.Cout * 384;  // bytes of packed weights per 32-channel chunk
+  auto a_tile = [&](int k) {   // lane offsets of tile k's weight pieces (past the last tile: out of range -> zeros)
+    const int m0 = tile_m0(k);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int idx = (tid & 255) + 256 * j;
+      const int row = (tid < 256 ? 64 : 0) + idx / 24, pq = idx % 24, kgh = pq / 12, q12 = pq % 12;
+      voffA[j] = (k < ntile && m0 + row < p.Cout) ? (unsigned)((kgh * p.Cout + m0 + row) * 192 + q12 * 16) : OOR;
+    }
+  };
+  int ka = 0, ca = 0;   // tile and chunk of the weight stream's next load
+  uint4v ra[NA];
+  auto load_a = [&]() {
+    const unsigned sA = (unsigned)ca * stepA;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = bufload4(rA, voffA[j], sA);
+    if (++ca == c_end) { ca = 0; a_tile(++ka); }
+  };
+  auto store_a = [&](int buf) {
+    unsigned char* dst = smem + buf * ABUF;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(dst + ldsA[j]) = ra[j];
+  };
 
-  // ---- positions: lane n16 owns the PAIR of positions n0 + 32 wave + 2 n16 + {0, 1}: column tile 0 = the even
-  // positions, column tile 1 = the odd ones.  One 8-byte load per channel fetches both (half the vector-memory
+  // ---- activation stream.  Lane n16 owns the PAIR of positions n0 + 32 wave + 2 n16 + {0, 1}: column tile 0 = the
+  // even positions, column tile 1 = the odd ones.  One 8-byte load per channel fetches both (half the vector-memory
   // instructions of one position per lane and tile), and a pixel's neighbour is mostly the OTHER column tile's value
   // in the same lane: left of (even, lane n) = (odd, lane n-1), right of it = (odd, lane n); left of (odd, lane n) =
   // (even, lane n), right of it = (even, lane n+1) -- two row shifts per channel pair instead of four.  W is even,
-  // so a pair never straddles an image row and both of its positions are valid or invalid together.
-  const long nj = n0 + wave * 32 + 2 * n16;
-  const bool nvalid = nj < p.Npos;
-  int pb = 0, py = 0, px = 0;
-  if (nvalid) {
-    pb = (int)(nj / p.HW);
-    const int pos = (int)(nj % p.HW);
-    py = pos / p.W;
-    px = pos % p.W;
-  }
+  // so a pair never straddles an image row and both of its positions are valid or invalid together.  A tile starts at
+  // a multiple of 256 positions and W divides 256: the column px -- and with it the border masks -- is the same in
+  // every tile; sample and row (pb, py) belong to the stream's current tile.
+  const int px = (wave * 32 + 2 * n16) % p.W;
   const bool has_left0 = px > 0, has_right1 = px + 2 < p.W;   // (even position's left tap, odd position's right tap)
-  constexpr int us = UP ? 1 : 0;   // input upsampled x2 on the fly (compile-time: the loads differ in width)
-  const unsigned chan_bytes = (unsigned)(p.HW >> (2 * us)) * 4;
-  unsigned voffB;
+  bool nvalid = false;
+  int pb = 0, py = 0;
+  auto b_tile = [&](int k) {
+    const long nj = tile_n0(k) + wave * 32 + 2 * n16;
+    nvalid = k < ntile && nj < p.Npos;
+    pb = py = 0;
+    if (nvalid) {
+      pb = (int)(nj / p.HW);
+      py = (int)(nj - (long)pb * p.HW) / p.W;
+    }
+  };
+  unsigned voffB = OOR;
   auto set_row = [&](int r) {
     const int iy = py + r - 1;
     const bool rok = nvalid && (unsigned)iy < (unsigned)p.H;
@@ -652,37 +703,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     if (us) off = ((long)pb * p.Cin + 8 * kg) * (p.HW >> 2) + (iy >> 1) * (p.W >> 1) + (px >> 1);
     voffB = rok ? (unsigned)(off * 4) : OOR;
   };
-
-  f32x4 acc[8][2];
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
-
-  const int nCB32 = p.nCB >> 1;
-  const int c_end = 3 * nCB32;
-  uint4v ra[NA];
-  float rb[2][8];   // [even | odd position][channel]
-  auto load_a = [&](int c, bool live) {
-    const unsigned sA = live ? (unsigned)c * stepA : OOR;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) ra[j] = bufload4(rA, voffA[j], sA);
-  };
-  auto store_a = [&](int buf) {
-    unsigned char* dst = smem + buf * ABUF;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(dst + ldsA[j]) = ra[j];
-  };
-  int cur_r = -1;
-  auto prep_b = [&](int c) {
-    const int r = c / nCB32, cb = c - r * nCB32;
-    if (r != cur_r && c < c_end) { set_row(r); cur_r = r; }
-    const unsigned dead = c < c_end ? 0u : OOR;
+  int kb = 0, rb_r = 0, rb_blk = 0;   // tile, kernel row and 32-channel block of the activation stream's next load
+  float rb[2][8];                      // [even | odd position][channel]
+  auto prep_b = [&]() {
+    if (rb_blk == 0) set_row(rb_r);   // a new kernel row (of a new tile, possibly)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const unsigned sB = (unsigned)(cb * 32 + j) * chan_bytes + dead;
+      const unsigned sB = (unsigned)(rb_blk * 32 + j) * chan_bytes;
       if (us) {
         rb[0][j] = bufload(rB, voffB, sB);
         rb[1][j] = rb[0][j];
@@ -694,12 +721,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
         rb[1][j] = __builtin_bit_cast(float, u1);
       }
     }
+    if (++rb_blk == nCB32) {
+      rb_blk = 0;
+      if (++rb_r == 3) { rb_r = 0; b_tile(++kb); }
+    }
   };
-  float s_in = 1.0f, omul = WSCALE_INV;
-  if (!SPLIT && p.in_scale != nullptr) {
-    s_in = p.in_scale[0];
-    omul = WSCALE_INV * p.in_scale[1];
-  }
   // fragments [tap][column tile] of one chunk out of the raw centre-tap registers: two conversions, two row shifts
   auto build_frags = [&](half8 (*fh)[2], half8 (*fl)[2]) {
     uint4v ch[2], cl[2];
@@ -739,96 +765,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     fl[2][1] = __builtin_bit_cast(half8, rl);
   };
 
-  // ---- main loop: the two waves of a SIMD ALTERNATE.  Waves 0-3 (one per SIMD) and waves 4-7 run half a period apart:
-  // while one group issues the 144 MFMAs of a chunk (with nothing but the weight-fragment reads between them) the other
-  // stages weights, builds its activation fragments and issues its loads -- each phase ends in a workgroup barrier.
-  // With both waves of a SIMD in the same phase (one barrier per chunk) the matrix pipe idles whenever both are in
-  // their staging part and is contended whenever both are in their MFMA part: measured 389 TF against 562 TF for the
-  // same loop with everything but the MFMAs compiled out (tools/r3_m16_ablate.sh).
-  //   phase 2c:   group 0 MFMA(c)      group 1 stages (chunk c-1's tail: weights c+1, fragments c, loads)
-  //   phase 2c+1: group 0 stages       group 1 MFMA(c)
-  // A weight stage is filled half by each group: stage c+1 by group 1 in phase 2c (its readers of chunk c-1 finished in
-  // 2c-1) and by group 0 in phase 2c+1 -- group 1 therefore runs its weight pipeline one chunk further ahead (`lead`).
-  // Row halves: group 1 stages rows 0-63, group 0 rows 64-127, so that at the END of its staging phase a group can
-  // already fetch the first fragment group of its next chunk (tap 0, rows 0-63: written by group 1 at least one
-  // barrier earlier) -- those reads land while the wave waits at the barrier instead of at the head of its MFMA phase
-  // (fetched after the barrier they cost ~10 % of the kernel: 8 reads x 4 waves queue on the LDS before one MFMA).
-  const int grp = wave >> 2, lead = 1 + grp;
-  if (!(p.ablate & 2)) {
-    half8 bh[3][2], bl[3][2];
-    // A fragments a GROUP ahead: group g = (tap g / 2, row tiles 4 (g & 1) .. +3): 8 ds_read_b128 that have the 24
-    // MFMAs (384 cycles) of the previous group to land
-    half8 af[2][4][2];
-    const int a_lane = n16 * ROWL + (kg ^ ((n16 >> 2) & 2)) * 16;
-    auto load_group = [&](int slot, int g, int c) {
-      if ((M16_ABL & 1) && (c > 0 || g > 1)) return;
-      const unsigned char* a = smem + (c & 1) * ABUF + a_lane + (g & 1) * 64 * ROWL + (g >> 1) * 64;
+  f32x4 acc[8][2];
+  auto zero_acc = [&]() {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        af[slot][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
-        af[slot][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
-      }
-    };
-    auto mfma_group = [&](int slot, int g) {
-      const int sx = g >> 1;
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int tq = 0; tq < 4; ++tq) {
-        const int t = (g & 1) * 4 + tq;
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][0], bh[sx][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][0], bh[sx][1], acc[t][1], 0, 0, 0);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][0], bl[sx][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][0], bl[sx][1], acc[t][1], 0, 0, 0);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][1], bh[sx][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][tq][1], bh[sx][1], acc[t][1], 0, 0, 0);
-      }
-    };
-    load_a(0, true);
-    prep_b(0);
-    store_a(0);
-    if (grp) load_a(1, 1 < c_end);
-    build_frags(bh, bl);
-    if (grp && 1 < c_end) store_a(1);
-    load_a(lead, lead < c_end);
-    prep_b(1);
-    __syncthreads();            // stage 0 complete
-    load_group(0, 0, 0);
-    if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
-    for (int c = 0; c < c_end; ++c) {
-      if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks its partner's staging (+1-2 %)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        // the next group's 8 fragment reads go out ONE per three MFMAs: issued as a block they hold the wave's
-        // instruction stream for ~50 cycles in which no MFMA issues and the matrix pipe runs dry (measured: 12 %)
-        if (g < 5) load_group((g + 1) & 1, g + 1, c);
-        mfma_group(g & 1, g);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
-      if (c + 1 == c_end) {       // last chunk: group 0 meets group 1's last staging barrier, group 1 just leaves
-        if (!grp) __syncthreads();
-        break;
-      }
-      __syncthreads();
-      // ---- staging phase
-      if (c + lead < c_end && !(M16_ABL & 4)) store_a((c + lead) & 1);
-      if (!(M16_ABL & 2)) build_frags(bh, bl);   // chunk c+1's fragments over chunk c's (their MFMAs have issued)
-      if (!(M16_ABL & 8)) {
-        load_a(c + lead + 1, c + lead + 1 < c_end);
-        prep_b(c + 2);
-      }
-      load_group(0, 0, c + 1);
-      __syncthreads();
-    }
-  }
-
-  // Epilogue.  Group 0 gets here one phase before group 1 and transposes through LDS while group 1 still reads the
-  // weight stage of the last chunk, and a fast wave is in the next tile's prologue while a slow one still transposes:
-  // the patches have an LDS area of their own behind the two stages.
+        for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
+  };
+  // Epilogue of tile k: the quad epilogue behind a functor that knows the accumulator layout.  The patches have an LDS
+  // area of their own behind the two weight stages (the other group reads a stage meanwhile).
   float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
   auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 2 n16 + ct
 #pragma unroll
@@ -842,10 +789,100 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
         *reinterpret_cast<f32x2*>(sc + (tt * 16 + 4 * kg + i) * EPI_PITCH + 2 * n16) = v2;
       }
   };
-  h2_epilogue_quad_put<4, true>(p, put, p.out, true, n0 + wave * 32, m0, lane, patches, p.ablate, omul);
-  // Next tile: group 0 fills stage 0 while group 1 may still be in its last MFMA phase, which reads the stage of the
-  // last chunk -- stage 1 for an even chunk count; an odd one (Cin = 96, 160, ...) needs the groups to meet first.
-  if (c_end & 1) __syncthreads();
+
+  // ---- main loop: the two waves of a SIMD ALTERNATE.  Waves 0-3 (one per SIMD) and waves 4-7 run half a period apart:
+  // while one group issues the 144 MFMAs of a chunk (with nothing but the weight-fragment reads between them) the other
+  // stages weights, builds its activation fragments and issues its loads -- each phase ends in a workgroup barrier.
+  // With both waves of a SIMD in the same phase (one barrier per chunk) the matrix pipe idles whenever both are in
+  // their staging part and is contended whenever both are in their MFMA part: measured 389 TF against 562 TF for the
+  // same loop with everything but the MFMAs compiled out (tools/r3_m16_ablate.sh).  s = chunk number over all tiles:
+  //   phase 2s:   group 0 MFMA(s)      group 1 stages (chunk s-1's tail: weights s+1, fragments s, loads)
+  //   phase 2s+1: group 0 stages       group 1 MFMA(s)
+  // A weight stage (s & 1) is filled half by each group: stage s+1 by group 1 in phase 2s (its readers of chunk s-1
+  // finished in 2s-1) and by group 0 in phase 2s+1 -- group 1 therefore runs its weight stream one chunk further
+  // ahead (`lead`).  Row halves: group 1 stages rows 0-63, group 0 rows 64-127, so that at the END of its staging phase
+  // a group can already fetch the first fragment group of its next chunk (tap 0, rows 0-63: written by group 1 at
+  // least one barrier earlier) -- those reads land while the wave waits at the barrier instead of at the head of its
+  // MFMA phase (fetched after the barrier they cost ~10 % of the kernel: 8 reads x 4 waves queue on the LDS before one
+  // MFMA).  After the last chunk of a tile the staging phase first stores the pending weight pieces, then runs the
+  // tile's epilogue (the accumulators, 80 registers of bias / residual and nothing else are live then) and clears the
+  // accumulators, then goes on as usual: the stage, fragment and load pipelines know nothing of tiles.
+  const int grp = wave >> 2, lead = 1 + grp;
+  half8 bh[3][2], bl[3][2];
+  // A fragments a GROUP ahead: group g = (tap g / 2, row tiles 4 (g & 1) .. +3): 8 ds_read_b128 that have the 24
+  // MFMAs (384 cycles) of the previous group to land
+  half8 af[2][4][2];
+  const int a_lane = n16 * ROWL + (kg ^ ((n16 >> 2) & 2)) * 16;
+  auto load_group = [&](int slot_, int g, int c) {
+    const unsigned char* a = smem + (c & 1) * ABUF + a_lane + (g & 1) * 64 * ROWL + (g >> 1) * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      af[slot_][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
+      af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
+    }
+  };
+  auto mfma_group = [&](int slot_, int g) {
+    const int sx = g >> 1;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+      const int t = (g & 1) * 4 + tq;
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][1], acc[t][1], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][1], acc[t][1], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][1], acc[t][1], 0, 0, 0);
+    }
+  };
+  a_tile(0);
+  b_tile(0);
+  zero_acc();
+  load_a();               // chunk 0
+  prep_b();               // chunk 0
+  store_a(0);
+  if (grp) load_a();      // chunk 1 (S >= 3)
+  build_frags(bh, bl);
+  if (grp) store_a(1);
+  load_a();               // group 0: chunk 1, group 1: chunk 2
+  prep_b();               // chunk 1
+  __syncthreads();        // stage 0 complete
+  load_group(0, 0, 0);
+  if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
+  int kc = 0, cc = 0;         // tile and chunk-in-tile of the MFMA phase
+  for (int s = 0;; ++s) {
+    if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks its partner's staging (+1-2 %)
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      // the next group's 8 fragment reads go out ONE per three MFMAs: issued as a block they hold the wave's
+      // instruction stream for ~50 cycles in which no MFMA issues and the matrix pipe runs dry (measured: 12 %)
+      if (g < 5) load_group((g + 1) & 1, g + 1, s);
+      mfma_group(g & 1, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
+    const bool last = s + 1 == S;
+    // (the very last chunk: group 0 meets group 1's last staging barrier, group 1 just leaves)
+    if (!last || !grp) __syncthreads();
+    // ---- staging phase
+    if (s + lead < S) store_a((s + lead) & 1);
+    if (++cc == c_end) {
+      h2_epilogue_quad_put<4, true>(p, put, p.out, true, tile_n0(kc) + wave * 32, tile_m0(kc), lane, patches, p.ablate,
+                                    omul);
+      zero_acc();
+      cc = 0;
+      ++kc;
+    }
+    if (last) break;
+    build_frags(bh, bl);   // chunk s+1's fragments over chunk s's (their MFMAs have issued)
+    load_a();
+    prep_b();
+    load_group(0, 0, s + 1);
+    __syncthreads();
   }
 }
 
@@ -941,6 +978,199 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_persist_kernel(ConvHParams 
       }
     }
     h2_epilogue_quad<4, false>(p, acc, p.out, true, (long)nt * BN + wave * 32, m0, lane, scratch, p.ablate, omul, bv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions with a LONG contraction (Cin >= 256: the qkv / proj convs of the 256-channel levels, the decoder's
+// skip convs over a channel concat) -- and the 128-channel ones that add a residual -- on v_mfma_f32_16x16x32_f16, in
+// the form of conv3x3_h2_m16_kernel: one persistent 8-wave workgroup per CU, the two waves of a SIMD alternating MFMA
+// and staging phases, weights streamed through two LDS stages, a lane owning a pair of positions (8-byte loads).
+// These layers ran at 205-250 TF on the tiled 32x32x16 kernel: neither at the matrix pipe's rate nor at HBM's.
+// A chunk = the packed layout's 64-channel chunk = 2 k-steps of 32 channels = 96 MFMAs per wave; its weight tile is
+// 128 rows x (hi 128 B + lo 128 B).  LDS rows are the bare 128 bytes (8 pieces of 16): a fragment read has lanes
+// (row n16, piece 4 ks + kg) and ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31},
+// ...: with pitch 128 the bank quad of a piece is 8 (row & 1) + piece, so piece ^= (row >> 1) & 7 spreads the sixteen
+// pieces of a group over the sixteen quads (rows {0,2,12,14} x kg 0 get XOR 0,1,6,7, rows {4,6,8,10} x kg 1 get
+// 2,3,4,5 on piece | 1: eight distinct values per row parity).
+// Channel concat (x | x2): a chunk comes from one source (Cin1 % 64 == 0, checked on the host).
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
+  constexpr int BM = 128, NT = 512, BN = 256;
+  constexpr int ROWL = 128;             // LDS row pitch in bytes: 64 halves
+  constexpr int ABUF = 2 * BM * ROWL;   // one weight stage: hi rows, then lo rows
+  constexpr int NA = BM * 16 / NT;      // 16-byte weight pieces per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kg = lane >> 4;
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)p.x2_bytes, 0x00020000);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int c_end = p.nCB, nc1 = p.Cin1 >> 6;   // chunks in all / from the first source
+  const int grp = wave >> 2, lead = 1 + grp;
+  float s_in = 1.0f, omul = WSCALE_INV;
+  if (!SPLIT && p.in_scale != nullptr) {
+    s_in = p.in_scale[0];
+    omul = WSCALE_INV * p.in_scale[1];
+  }
+  const unsigned chan_bytes = (unsigned)p.HW * 4;
+  const unsigned stepA = (unsigned)p.Cout * 256;  // bytes of packed weights per chunk
+  for (int q = slot;; q += nslots) {   // tile order: see conv3x3_h2_m16_kernel
+  const int mt = q % p.mtiles;
+  const long nt = (long)(q / p.mtiles) * 8 + xcd;
+  const int m0 = mt * BM;
+  const long n0 = nt * BN;
+  if (n0 >= p.Npos) break;
+
+  // weight pieces: waves 4-7 stage rows 0-63, waves 0-3 rows 64-127; a row's 16 pieces = hi 0-7 | lo 8-15
+  unsigned voffA[NA];
+  int ldsA[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int idx = (tid & 255) + 256 * j;
+    const int row = (tid < 256 ? 64 : 0) + (idx >> 4), q16 = idx & 15;
+    voffA[j] = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * 256 + q16 * 16) : OOR;
+    ldsA[j] = ((q16 >> 3) * BM + row) * ROWL + (((q16 & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  // positions: lane n16 owns the pair n0 + 32 wave + 2 n16 + {0, 1} (HW is a multiple of 4: never across samples)
+  const long nj = n0 + wave * 32 + 2 * n16;
+  const bool nvalid = nj < p.Npos;
+  unsigned voffB1 = OOR, voffB2 = OOR;
+  if (nvalid) {
+    const int pb = (int)(nj / p.HW), pos = (int)(nj - (long)pb * p.HW);
+    voffB1 = (unsigned)((((long)pb * p.Cin1 + 8 * kg) * p.HW + pos) * 4);
+    if (p.x2) voffB2 = (unsigned)((((long)pb * (p.Cin - p.Cin1) + 8 * kg) * p.HW + pos) * 4);
+  }
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
+
+  uint4v ra[NA];
+  float rb[2][2][8];   // [k-step][even | odd position][channel]
+  auto load_a = [&](int c, bool live) {
+    const unsigned sA = live ? (unsigned)c * stepA : OOR;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = bufload4(rA, voffA[j], sA);
+  };
+  auto store_a = [&](int buf) {
+    unsigned char* dst = smem + buf * ABUF;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(dst + ldsA[j]) = ra[j];
+  };
+  auto prep_b = [&](int c) {
+    const bool first = c < nc1;   // workgroup-uniform: scalar selects, no branch
+    const unsigned cbase = (unsigned)((first ? c : c - nc1) * 64);
+    const unsigned dead = c < c_end ? 0u : OOR;
+    const unsigned voff = first ? voffB1 : voffB2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+        const unsigned sB = (cbase + ks * 32 + j) * chan_bytes + dead;
+        const uint2v v2 = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(first ? rB : rB2, voff, sB, 0));
+        const unsigned u0 = v2.x, u1 = v2.y;
+        rb[ks][0][j] = __builtin_bit_cast(float, u0);
+        rb[ks][1][j] = __builtin_bit_cast(float, u1);
+      }
+  };
+  auto build_frags = [&](half8 (*fh)[2], half8 (*fl)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        if (SPLIT) unpack8(rb[ks][ct], fh[ks][ct], fl[ks][ct]);
+        else split8s(rb[ks][ct], s_in, fh[ks][ct], fl[ks][ct]);
+      }
+  };
+
+  if (!(p.ablate & 2)) {
+    half8 bh[2][2], bl[2][2];
+    // A fragments a GROUP ahead: group g = (k-step g / 2, row tiles 4 (g & 1) .. +3), 8 ds_read_b128 per group
+    half8 af[2][4][2];
+    const int a_lane[2] = {n16 * ROWL + ((kg ^ (n16 >> 1)) << 4), n16 * ROWL + (((4 + kg) ^ (n16 >> 1)) << 4)};
+    auto load_group = [&](int slot_, int g, int c) {
+      const unsigned char* a = smem + (c & 1) * ABUF + a_lane[g >> 1] + (g & 1) * 64 * ROWL;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        af[slot_][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
+        af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
+      }
+    };
+    auto mfma_group = [&](int slot_, int g) {
+      const int ks = g >> 1;
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int t = (g & 1) * 4 + tq;
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][1], acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][1], acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][1], acc[t][1], 0, 0, 0);
+      }
+    };
+    // phases and barriers exactly as in conv3x3_h2_m16_kernel (group 1 runs its weight pipeline `lead` = 2 ahead)
+    load_a(0, true);
+    prep_b(0);
+    store_a(0);
+    if (grp) load_a(1, 1 < c_end);
+    build_frags(bh, bl);
+    if (grp && 1 < c_end) store_a(1);
+    load_a(lead, lead < c_end);
+    prep_b(1);
+    __syncthreads();            // stage 0 complete
+    load_group(0, 0, 0);
+    if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
+    for (int c = 0; c < c_end; ++c) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < 3) load_group((g + 1) & 1, g + 1, c);
+        mfma_group(g & 1, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (c + 1 == c_end) {
+        if (!grp) __syncthreads();
+        break;
+      }
+      __syncthreads();
+      // ---- staging phase
+      if (c + lead < c_end) store_a((c + lead) & 1);
+      build_frags(bh, bl);
+      load_a(c + lead + 1, c + lead + 1 < c_end);
+      prep_b(c + 2);
+      load_group(0, 0, c + 1);
+      __syncthreads();
+    }
+  }
+
+  float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
+  auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 2 n16 + ct
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));   // (not HIP's float2 struct: see the 3x3 kernel)
+        const f32x2 v2 = {acc[2 * T + tt][0][i], acc[2 * T + tt][1][i]};
+        *reinterpret_cast<f32x2*>(sc + (tt * 16 + 4 * kg + i) * EPI_PITCH + 2 * n16) = v2;
+      }
+  };
+  h2_epilogue_quad_put<4, true>(p, put, p.out, true, n0 + wave * 32, m0, lane, patches, p.ablate, omul);
+  if (c_end & 1) __syncthreads();   // (odd chunk count: the groups meet before stage 0 is refilled)
   }
 }
 
@@ -1275,6 +1505,32 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
     else H2_PERSIST(false);
 #undef H2_PERSIST
     return i2r_check_launch("conv1x1_h2_persist");
+  }
+  // long-K (or residual-adding) 1x1 layers at inference sizes: the 16x16x32 MFMA form (conv1x1_h2_m16_kernel)
+  {
+    const char* m16k1 = getenv("I2R_H2_M16_K1");  // (read per call: A/B probes and tests flip it inside one process)
+    static const long k1_mintiles = getenv("I2R_H2_M16_MINTILES") ? atol(getenv("I2R_H2_M16_MINTILES")) : 256;
+    if (ksize == 1 && (m16k1 && atoi(m16k1) == 1) && !one_term && !up_in && Cin % 64 == 0 && Cin >= 128 &&
+        (!x2 || Cin1 % 64 == 0) && Cout > 64 && (W & 3) == 0 &&
+        (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= k1_mintiles) {
+      const int lds = 2 * 2 * 128 * 128 + 8 * 32 * EPI_PITCH * 4;
+      p.mtiles = i2r_cdiv(Cout, 128);
+      const long per_xcd = (long)((i2r_cdiv(Npos, 256) + 7) / 8) * p.mtiles;
+      dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));  // one workgroup per CU
+      p.out = out;   // (never split-K)
+      p.nsplit = 1;
+#define H2_M16_K1(SP_)                                                          \
+  do {                                                                          \
+    auto kern = conv1x1_h2_m16_kernel<SP_>;                                     \
+    static bool attr[64] = {false};                                             \
+    if (!i2r_lds_attr((const void*)kern, lds, attr)) return I2R_ERR_HIP;        \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);                       \
+  } while (0)
+      if (x_is_split) H2_M16_K1(true);
+      else H2_M16_K1(false);
+#undef H2_M16_K1
+      return i2r_check_launch("conv1x1_h2_m16");
+    }
   }
   // 3x3 convs with few output channels run on a shorter Cout tile (the MFMAs of the empty rows are not issued)
   const int bm = (ksize == 3 && !one_term && !getenv("I2R_H2_BM128")) ? (Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128) : 128;
