@@ -187,7 +187,7 @@ __device__ __forceinline__ void h2_quad_bias(const ConvHParams& p, bool full, in
 template <int NTL, bool RES, typename PUT>
 __device__ __forceinline__ void h2_epilogue_quad_put(const ConvHParams& p, PUT put, float* outp, bool full,
                                                      long nw, int m0, int lane, float* scratch, int ablate, float omul,
-                                                     const float* bias_pre = nullptr) {
+                                                     const float* bias_pre = nullptr, const float* bias_lds = nullptr) {
   const int cr = lane >> 3, pq = (lane & 7) * 4;
   const long nq = nw + pq;
   const bool qvalid = nq < p.Npos;
@@ -221,10 +221,13 @@ __device__ __forceinline__ void h2_epilogue_quad_put(const ConvHParams& p, PUT p
   if (bias_pre) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bv[q] = bias_pre[q];
+  } else if (bias_lds) {   // the tile's bias values (zeros where there is none) staged in LDS by the caller
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bv[q] = bias_lds[8 * q + cr];
   } else {
     h2_quad_bias<NQ>(p, full, m0, lane, bv);
   }
-  if (!RES) {
+  if (!RES || !use_res) {   // (uniform branch: without a residual not even the null-descriptor loads are issued)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -249,11 +252,14 @@ __device__ __forceinline__ void h2_epilogue_quad_put(const ConvHParams& p, PUT p
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
     put(t, scratch);
+    // the four reads of a block go out together (one LDS round trip per block instead of four in a row)
+    f32x4 a4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(scratch + (8 * i + cr) * EPI_PITCH + pq);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = 4 * t + i, cof = 8 * q;
-      const float4 a = *reinterpret_cast<const float4*>(scratch + (8 * i + cr) * EPI_PITCH + pq);
-      float v[4] = {a.x, a.y, a.z, a.w};
+      float v[4] = {a4[i][0], a4[i][1], a4[i][2], a4[i][3]};
       uint4v o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -777,6 +783,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   // Epilogue of tile k: the quad epilogue behind a functor that knows the accumulator layout.  The patches have an LDS
   // area of their own behind the two weight stages (the other group reads a stage meanwhile).
   float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
+  // the bias of every output-channel tile (zeros where there is none) in LDS, once per workgroup: the epilogue then
+  // starts without a global-memory round trip (16 dword loads and their latency per tile and wave)
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * ABUF) + 8 * 32 * EPI_PITCH;
+  for (int i = tid; i < p.mtiles * BM; i += NT) bias_lds[i] = (p.bias != nullptr && i < p.Cout) ? p.bias[i] : 0.0f;
   auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 2 n16 + ct
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -871,8 +881,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     // ---- staging phase
     if (s + lead < S) store_a((s + lead) & 1);
     if (++cc == c_end) {
-      h2_epilogue_quad_put<4, true>(p, put, p.out, true, tile_n0(kc) + wave * 32, tile_m0(kc), lane, patches, p.ablate,
-                                    omul);
+      if (!(p.ablate & 128) || last)   // (128: timing experiment -- only the last tile's epilogue runs)
+        h2_epilogue_quad_put<4, true>(p, put, p.out, true, tile_n0(kc) + wave * 32, tile_m0(kc), lane, patches,
+                                      p.ablate, omul, nullptr, bias_lds + tile_m0(kc));
       zero_acc();
       cc = 0;
       ++kc;
@@ -1007,8 +1018,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
   __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rB2 =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)p.x2_bytes, 0x00020000);
+  // tiles and the one software pipeline over all their chunks: see conv3x3_h2_m16_kernel
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int c_end = p.nCB, nc1 = p.Cin1 >> 6;   // chunks in all / from the first source
+  const long npt = (p.Npos + BN - 1) / BN;
+  const long lim = (npt > xcd ? (npt - xcd + 7) / 8 : 0) * p.mtiles;
+  const int ntile = lim > slot ? (int)((lim - slot + nslots - 1) / nslots) : 0;
+  if (ntile == 0) return;   // (whole workgroup, before any barrier)
+  const int c_end = p.nCB, nc1 = p.Cin1 >> 6;   // chunks per tile / of them from the first source
+  const int S = ntile * c_end;
   const int grp = wave >> 2, lead = 1 + grp;
   float s_in = 1.0f, omul = WSCALE_INV;
   if (!SPLIT && p.in_scale != nullptr) {
@@ -1017,69 +1034,84 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
   }
   const unsigned chan_bytes = (unsigned)p.HW * 4;
   const unsigned stepA = (unsigned)p.Cout * 256;  // bytes of packed weights per chunk
-  for (int q = slot;; q += nslots) {   // tile order: see conv3x3_h2_m16_kernel
-  const int mt = q % p.mtiles;
-  const long nt = (long)(q / p.mtiles) * 8 + xcd;
-  const int m0 = mt * BM;
-  const long n0 = nt * BN;
-  if (n0 >= p.Npos) break;
+  auto tile_m0 = [&](int k) { return ((slot + k * nslots) % p.mtiles) * BM; };
+  auto tile_n0 = [&](int k) { return ((long)((slot + k * nslots) / p.mtiles) * 8 + xcd) * BN; };
 
-  // weight pieces: waves 4-7 stage rows 0-63, waves 0-3 rows 64-127; a row's 16 pieces = hi 0-7 | lo 8-15
+  // ---- weight stream: waves 4-7 stage rows 0-63, waves 0-3 rows 64-127; a row's 16 pieces = hi 0-7 | lo 8-15
   unsigned voffA[NA];
   int ldsA[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int idx = (tid & 255) + 256 * j;
     const int row = (tid < 256 ? 64 : 0) + (idx >> 4), q16 = idx & 15;
-    voffA[j] = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * 256 + q16 * 16) : OOR;
     ldsA[j] = ((q16 >> 3) * BM + row) * ROWL + (((q16 & 7) ^ ((row >> 1) & 7)) << 4);
   }
-  // positions: lane n16 owns the pair n0 + 32 wave + 2 n16 + {0, 1} (HW is a multiple of 4: never across samples)
-  const long nj = n0 + wave * 32 + 2 * n16;
-  const bool nvalid = nj < p.Npos;
-  unsigned voffB1 = OOR, voffB2 = OOR;
-  if (nvalid) {
-    const int pb = (int)(nj / p.HW), pos = (int)(nj - (long)pb * p.HW);
-    voffB1 = (unsigned)((((long)pb * p.Cin1 + 8 * kg) * p.HW + pos) * 4);
-    if (p.x2) voffB2 = (unsigned)((((long)pb * (p.Cin - p.Cin1) + 8 * kg) * p.HW + pos) * 4);
-  }
-
-  f32x4 acc[8][2];
+  auto a_tile = [&](int k) {
+    const int m0 = tile_m0(k);
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
-
+    for (int j = 0; j < NA; ++j) {
+      const int idx = (tid & 255) + 256 * j;
+      const int row = (tid < 256 ? 64 : 0) + (idx >> 4), q16 = idx & 15;
+      voffA[j] = (k < ntile && m0 + row < p.Cout) ? (unsigned)((m0 + row) * 256 + q16 * 16) : OOR;
+    }
+  };
+  int ka = 0, ca = 0;
   uint4v ra[NA];
-  float rb[2][2][8];   // [k-step][even | odd position][channel]
-  auto load_a = [&](int c, bool live) {
-    const unsigned sA = live ? (unsigned)c * stepA : OOR;
+  auto load_a = [&]() {
+    const unsigned sA = (unsigned)ca * stepA;
 #pragma unroll
     for (int j = 0; j < NA; ++j) ra[j] = bufload4(rA, voffA[j], sA);
+    if (++ca == c_end) { ca = 0; a_tile(++ka); }
   };
   auto store_a = [&](int buf) {
     unsigned char* dst = smem + buf * ABUF;
 #pragma unroll
     for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4v*>(dst + ldsA[j]) = ra[j];
   };
-  auto prep_b = [&](int c) {
-    const bool first = c < nc1;   // workgroup-uniform: scalar selects, no branch
-    const unsigned cbase = (unsigned)((first ? c : c - nc1) * 64);
-    const unsigned dead = c < c_end ? 0u : OOR;
+
+  // ---- activation stream: lane n16 owns the pair n0 + 32 wave + 2 n16 + {0, 1} (HW % 4 == 0: never across samples)
+  unsigned voffB1 = OOR, voffB2 = OOR;
+  auto b_tile = [&](int k) {
+    const long nj = tile_n0(k) + wave * 32 + 2 * n16;
+    voffB1 = voffB2 = OOR;
+    if (k < ntile && nj < p.Npos) {
+      const int pb = (int)(nj / p.HW), pos = (int)(nj - (long)pb * p.HW);
+      voffB1 = (unsigned)((((long)pb * p.Cin1 + 8 * kg) * p.HW + pos) * 4);
+      if (p.x2) voffB2 = (unsigned)((((long)pb * (p.Cin - p.Cin1) + 8 * kg) * p.HW + pos) * 4);
+    }
+  };
+  int kb = 0, cb = 0;
+  float rb[2][2][8];   // [k-step][even | odd position][channel]
+  auto prep_b = [&]() {
+    const bool first = cb < nc1;   // workgroup-uniform
+    const unsigned cbase = (unsigned)((first ? cb : cb - nc1) * 64);
     const unsigned voff = first ? voffB1 : voffB2;
+    if (first) {   // (a uniform branch, not a select of the descriptor: that would put it into vector registers)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-        const unsigned sB = (cbase + ks * 32 + j) * chan_bytes + dead;
-        const uint2v v2 = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(first ? rB : rB2, voff, sB, 0));
-        const unsigned u0 = v2.x, u1 = v2.y;
-        rb[ks][0][j] = __builtin_bit_cast(float, u0);
-        rb[ks][1][j] = __builtin_bit_cast(float, u1);
-      }
+        for (int j = 0; j < 8; ++j) {
+          typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+          const uint2v v2 = __builtin_bit_cast(
+              uint2v, __builtin_amdgcn_raw_buffer_load_b64(rB, voff, (cbase + ks * 32 + j) * chan_bytes, 0));
+          const unsigned u0 = v2.x, u1 = v2.y;
+          rb[ks][0][j] = __builtin_bit_cast(float, u0);
+          rb[ks][1][j] = __builtin_bit_cast(float, u1);
+        }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+          const uint2v v2 = __builtin_bit_cast(
+              uint2v, __builtin_amdgcn_raw_buffer_load_b64(rB2, voff, (cbase + ks * 32 + j) * chan_bytes, 0));
+          const unsigned u0 = v2.x, u1 = v2.y;
+          rb[ks][0][j] = __builtin_bit_cast(float, u0);
+          rb[ks][1][j] = __builtin_bit_cast(float, u1);
+        }
+    }
+    if (++cb == c_end) { cb = 0; b_tile(++kb); }
   };
   auto build_frags = [&](half8 (*fh)[2], half8 (*fl)[2]) {
 #pragma unroll
@@ -1091,74 +1123,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
       }
   };
 
-  if (!(p.ablate & 2)) {
-    half8 bh[2][2], bl[2][2];
-    // A fragments a GROUP ahead: group g = (k-step g / 2, row tiles 4 (g & 1) .. +3), 8 ds_read_b128 per group
-    half8 af[2][4][2];
-    const int a_lane[2] = {n16 * ROWL + ((kg ^ (n16 >> 1)) << 4), n16 * ROWL + (((4 + kg) ^ (n16 >> 1)) << 4)};
-    auto load_group = [&](int slot_, int g, int c) {
-      const unsigned char* a = smem + (c & 1) * ABUF + a_lane[g >> 1] + (g & 1) * 64 * ROWL;
+  f32x4 acc[8][2];
+  auto zero_acc = [&]() {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        af[slot_][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
-        af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
-      }
-    };
-    auto mfma_group = [&](int slot_, int g) {
-      const int ks = g >> 1;
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int tq = 0; tq < 4; ++tq) {
-        const int t = (g & 1) * 4 + tq;
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][1], acc[t][1], 0, 0, 0);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][1], acc[t][1], 0, 0, 0);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][1], acc[t][1], 0, 0, 0);
-      }
-    };
-    // phases and barriers exactly as in conv3x3_h2_m16_kernel (group 1 runs its weight pipeline `lead` = 2 ahead)
-    load_a(0, true);
-    prep_b(0);
-    store_a(0);
-    if (grp) load_a(1, 1 < c_end);
-    build_frags(bh, bl);
-    if (grp && 1 < c_end) store_a(1);
-    load_a(lead, lead < c_end);
-    prep_b(1);
-    __syncthreads();            // stage 0 complete
-    load_group(0, 0, 0);
-    if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
-    for (int c = 0; c < c_end; ++c) {
-      __builtin_amdgcn_s_setprio(1);
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < 3) load_group((g + 1) & 1, g + 1, c);
-        mfma_group(g & 1, g);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (c + 1 == c_end) {
-        if (!grp) __syncthreads();
-        break;
-      }
-      __syncthreads();
-      // ---- staging phase
-      if (c + lead < c_end) store_a((c + lead) & 1);
-      build_frags(bh, bl);
-      load_a(c + lead + 1, c + lead + 1 < c_end);
-      prep_b(c + 2);
-      load_group(0, 0, c + 1);
-      __syncthreads();
-    }
-  }
-
+        for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
+  };
   float* patches = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * EPI_PITCH);
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * ABUF) + 8 * 32 * EPI_PITCH;
+  for (int i = tid; i < p.mtiles * BM; i += NT) bias_lds[i] = (p.bias != nullptr && i < p.Cout) ? p.bias[i] : 0.0f;
   auto put = [&](int T, float* sc) {  // acc[t][ct][i] = channel 16 t + 4 kg + i, position 2 n16 + ct
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -1169,8 +1145,79 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
         *reinterpret_cast<f32x2*>(sc + (tt * 16 + 4 * kg + i) * EPI_PITCH + 2 * n16) = v2;
       }
   };
-  h2_epilogue_quad_put<4, true>(p, put, p.out, true, n0 + wave * 32, m0, lane, patches, p.ablate, omul);
-  if (c_end & 1) __syncthreads();   // (odd chunk count: the groups meet before stage 0 is refilled)
+
+  half8 bh[2][2], bl[2][2];
+  // A fragments a GROUP ahead: group g = (k-step g / 2, row tiles 4 (g & 1) .. +3), 8 ds_read_b128 per group
+  half8 af[2][4][2];
+  const int a_lane[2] = {n16 * ROWL + ((kg ^ (n16 >> 1)) << 4), n16 * ROWL + (((4 + kg) ^ (n16 >> 1)) << 4)};
+  auto load_group = [&](int slot_, int g, int c) {
+    const unsigned char* a = smem + (c & 1) * ABUF + a_lane[g >> 1] + (g & 1) * 64 * ROWL;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      af[slot_][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
+      af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
+    }
+  };
+  auto mfma_group = [&](int slot_, int g) {
+    const int ks = g >> 1;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+      const int t = (g & 1) * 4 + tq;
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[ks][1], acc[t][1], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[ks][1], acc[t][1], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[ks][1], acc[t][1], 0, 0, 0);
+    }
+  };
+  // phases and barriers exactly as in conv3x3_h2_m16_kernel (group 1 runs its weight stream `lead` = 2 ahead)
+  a_tile(0);
+  b_tile(0);
+  zero_acc();
+  load_a();               // chunk 0
+  prep_b();               // chunk 0
+  store_a(0);
+  if (grp) load_a();      // chunk 1 (S >= 2)
+  build_frags(bh, bl);
+  if (grp) store_a(1);
+  load_a();               // group 0: chunk 1, group 1: chunk 2
+  prep_b();               // chunk 1
+  __syncthreads();        // stage 0 (and the bias) complete
+  load_group(0, 0, 0);
+  if (grp) __syncthreads();   // phase 0: group 0 computes chunk 0
+  int kc = 0, cc = 0;
+  for (int s = 0;; ++s) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) load_group((g + 1) & 1, g + 1, s);
+      mfma_group(g & 1, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const bool last = s + 1 == S;
+    if (!last || !grp) __syncthreads();
+    // ---- staging phase
+    if (s + lead < S) store_a((s + lead) & 1);
+    if (++cc == c_end) {
+      h2_epilogue_quad_put<4, true>(p, put, p.out, true, tile_n0(kc) + wave * 32, tile_m0(kc), lane, patches, p.ablate,
+                                    omul, nullptr, bias_lds + tile_m0(kc));
+      zero_acc();
+      cc = 0;
+      ++kc;
+    }
+    if (last) break;
+    build_frags(bh, bl);
+    load_a();
+    prep_b();
+    load_group(0, 0, s + 1);
+    __syncthreads();
   }
 }
 
@@ -1510,11 +1557,11 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   {
     const char* m16k1 = getenv("I2R_H2_M16_K1");  // (read per call: A/B probes and tests flip it inside one process)
     static const long k1_mintiles = getenv("I2R_H2_M16_MINTILES") ? atol(getenv("I2R_H2_M16_MINTILES")) : 256;
-    if (ksize == 1 && (m16k1 && atoi(m16k1) == 1) && !one_term && !up_in && Cin % 64 == 0 && Cin >= 128 &&
-        (!x2 || Cin1 % 64 == 0) && Cout > 64 && (W & 3) == 0 &&
+    if (ksize == 1 && !(m16k1 && atoi(m16k1) == 0) && !one_term && !up_in && Cin % 64 == 0 && Cin >= 128 &&
+        (!x2 || Cin1 % 64 == 0) && Cout > 64 && Cout <= 2048 && (W & 3) == 0 &&
         (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= k1_mintiles) {
-      const int lds = 2 * 2 * 128 * 128 + 8 * 32 * EPI_PITCH * 4;
       p.mtiles = i2r_cdiv(Cout, 128);
+      const int lds = 2 * 2 * 128 * 128 + 8 * 32 * EPI_PITCH * 4 + p.mtiles * 512;  // stages, patches, bias
       const long per_xcd = (long)((i2r_cdiv(Npos, 256) + 7) / 8) * p.mtiles;
       dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));  // one workgroup per CU
       p.out = out;   // (never split-K)
@@ -1523,7 +1570,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   do {                                                                          \
     auto kern = conv1x1_h2_m16_kernel<SP_>;                                     \
     static bool attr[64] = {false};                                             \
-    if (!i2r_lds_attr((const void*)kern, lds, attr)) return I2R_ERR_HIP;        \
+    if (!i2r_lds_attr((const void*)kern, lds - p.mtiles * 512 + 16 * 512, attr)) return I2R_ERR_HIP; \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);                       \
   } while (0)
       if (x_is_split) H2_M16_K1(true);
@@ -1540,10 +1587,10 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   static const long m16_mintiles = getenv("I2R_H2_M16_MINTILES") ? atol(getenv("I2R_H2_M16_MINTILES")) : 256;
   const bool m16_size = (bn == 256 && nsplit == 1) ||
                         (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= m16_mintiles;
-  if (ksize == 3 && !(m16 && atoi(m16) == 0) && !one_term && !x2 && bm == 128 && Cout > 64 && m16_size &&
+  if (ksize == 3 && !(m16 && atoi(m16) == 0) && !one_term && !x2 && bm == 128 && Cout > 64 && Cout <= 2048 && m16_size &&
       Cin % 32 == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || (W == 2 && H == 2 && !up_in && !up_res)) &&
       !getenv("I2R_H2_NODPP")) {
-    const int lds = 2 * 2 * 128 * (96 * 2) + 8 * 32 * EPI_PITCH * 4;
+    const int lds = 2 * 2 * 128 * (96 * 2) + 8 * 32 * EPI_PITCH * 4 + p.mtiles * 128 * 4;  // stages, patches, bias
     const long per_xcd = (long)((i2r_cdiv(Npos, 256) + 7) / 8) * p.mtiles;  // tile-list entries of one XCD
     dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));                // one workgroup per CU
     p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
@@ -1552,7 +1599,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   do {                                                                                                          \
     auto kern = conv3x3_h2_m16_kernel<SP_, WM_, UP_>;                                                           \
     static bool attr[64] = {false};                                                                             \
-    if (!i2r_lds_attr((const void*)kern, lds, attr)) return I2R_ERR_HIP;                                        \
+    if (!i2r_lds_attr((const void*)kern, lds - p.mtiles * 512 + 16 * 512, attr)) return I2R_ERR_HIP;            \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);                                                       \
   } while (0)
 #define H2_M16_W(SP_)                                  \

@@ -33,6 +33,8 @@ def test_bits_equal_the_tiled_kernel(case):
     wph = ops.conv2d_pack_h2(w)
     out = {}
     before = os.environ.get("I2R_H2_PERSIST")
+    before_k1 = os.environ.get("I2R_H2_M16_K1")
+    os.environ["I2R_H2_M16_K1"] = "0"   # the TILED kernel is the reference (not the 16x16x32 form of the larger launches)
     try:
         for mode in ("0", "1"):
             os.environ["I2R_H2_PERSIST"] = mode
@@ -42,6 +44,10 @@ def test_bits_equal_the_tiled_kernel(case):
             os.environ.pop("I2R_H2_PERSIST", None)
         else:
             os.environ["I2R_H2_PERSIST"] = before
+        if before_k1 is None:
+            os.environ.pop("I2R_H2_M16_K1", None)
+        else:
+            os.environ["I2R_H2_M16_K1"] = before_k1
     assert torch.equal(out["0"].view(torch.int32), out["1"].view(torch.int32))
     if not qo:
         ref = torch.nn.functional.conv2d(x0.double(), w.double(), b.double())
