@@ -80,7 +80,10 @@ _KNOBS = {
     "no_fuse_up": bool(os.environ.get("I2R_NO_FUSE_UP")),            # materialise the decoder's x2 upsample
     "no_gn_bypass": bool(os.environ.get("I2R_NO_GN_BYPASS")),        # training: residual branch outside GroupNorm
     "no_qkv_presplit": bool(os.environ.get("I2R_NO_QKV_PRESPLIT")),  # attention splits q,k,v itself
-    "attn_chunk_bytes": float(os.environ.get("I2R_ATTN_CHUNK_MB", 256)) * 1e6,  # qkv bytes per attention-tail chunk
+    # qkv bytes per attention-tail chunk.  256 MB (one infinity cache) until round 3; measured then: 256 -> 1024 MB / off
+    # B1 1672 -> 1697 series/s, D 383 -> 390 (the chunks' small launches cost more than the cache returns); 1024 MB keeps
+    # every chunk's qkv tensor under the kernels' 2 GiB addressing limit whatever the batch.
+    "attn_chunk_bytes": float(os.environ.get("I2R_ATTN_CHUNK_MB", 1024)) * 1e6,
 }
 
 
