@@ -861,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
   int kc = 0, cc = 0;         // tile and chunk-in-tile of the MFMA phase
   for (int s = 0;; ++s) {
     if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks its partner's staging (+1-2 %)
+    const bool last = s + 1 == S;
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
       // the next group's 8 fragment reads go out ONE per three MFMAs: issued as a block they hold the wave's
@@ -875,8 +876,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
-    const bool last = s + 1 == S;
-    // (the very last chunk: group 0 meets group 1's last staging barrier, group 1 just leaves)
+    // (the very last chunk: group 0 meets group 1's last staging barrier, group 1 just leaves.  The barrier one MFMA
+    // group EARLIER, so that the other group's first MFMAs issue beside this group's last 24 instead of after a barrier
+    // round trip: measured 6-7 % SLOWER on three bench shapes -- the groups' MFMAs contend, they do not interleave)
     if (!last || !grp) __syncthreads();
     // ---- staging phase
     if (s + lead < S) store_a((s + lead) & 1);
