@@ -1223,6 +1223,246 @@ __global__ __launch_bounds__(512, 2) void conv1x1_h2_m16_kernel(ConvHParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the weight-stationary 16x16x32 kernel below, straight from the accumulators (no LDS): with the pair
+// layout acc[t][ct][i] of lane (n16, kg) = channel 16 t + 4 kg + i, position 2 n16 + ct -- the two column tiles of a
+// lane are two ADJACENT positions of one channel, so (acc[t][0][i], acc[t][1][i]) is one 8-byte store and the sixteen
+// lanes n16 of a channel write one 128-byte run per instruction.  32 store instructions per wave and slice (the
+// transposing quad epilogue: 16) -- affordable where waves are decoupled and one wave's epilogue runs beside another
+// wave's MFMAs; in the lock-step kernels above this form measured no better than the quad epilogue.
+// The residual is loaded one channel block ahead (a lane reads exactly the elements it writes: an output that IS the
+// residual's buffer stays correct).  `bias_tile`: the tile's 128 bias values in LDS (zeros where there is none).
+template <bool HAS_RES, bool QKV>
+__device__ __forceinline__ void ws_epilogue_pairs(const ConvHParams& p, const f32x4 (&acc)[8][2], long nw, int m0,
+                                                  int lane, int ablate, float omul, const float* bias_tile) {
+  typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+  const int n16 = lane & 15, kg = lane >> 4;
+  const unsigned out_bytes = (unsigned)(p.Npos * p.Cout * 4);
+  const unsigned HWu = (unsigned)p.HW, plane = HWu * 4;
+  const int c0 = m0 + 4 * kg;                    // this lane's channel for (t, i): c0 + 16 t + i
+  const long nq = nw + 2 * n16;                  // its position pair (never across samples: HW is even)
+  const bool pvalid = nq < p.Npos;
+  unsigned pb = 0, pos = 0;
+  if (pvalid) {   // (32-bit: positions stay below 2^29 -- the host checks out_bytes < 2 GiB)
+    pb = (unsigned)nq / HWu;
+    pos = (unsigned)nq - pb * HWu;
+  }
+  const unsigned voff = pvalid ? ((pb * (unsigned)p.Cout + (unsigned)c0) * HWu + pos) * 4u : OOR;
+  __amdgpu_buffer_rsrc_t rO =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, __builtin_amdgcn_readfirstlane((int)out_bytes), 0x00020000);
+  __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.res, 0, __builtin_amdgcn_readfirstlane(HAS_RES ? (int)out_bytes : 0), 0x00020000);
+  const int lim = p.Cout - c0;                   // channel offsets 16 t + i below lim exist for this lane
+  const int cmod = c0 % 3;
+  auto load_res = [&](int t, uint2v (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      r[i] = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rR, 16 * t + i < lim ? voff : OOR,
+                                                                             (unsigned)(16 * t + i) * plane, 0));
+  };
+  uint2v rcur[4], rnext[4];
+  if (HAS_RES && !(ablate & 16)) load_res(0, rcur);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (HAS_RES && (ablate & 16)) load_res(t, rcur);   // (debug: no prefetch)
+    if (HAS_RES && !(ablate & 16) && t + 1 < 8) load_res(t + 1, rnext);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_tile + 16 * t + 4 * kg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cof = 16 * t + i;
+      // (the bias through two separately laundered copies: left alone, the compiler packs the two fmas into one
+      // v_pk_fma_f32 that broadcasts the bias register pair's high element through op_sel -- and on gfx950 the LOW
+      // result took the low element instead in lanes 48-63 now and then, right behind a v_mov into the packed source:
+      // element 0 of a pair got its neighbour channel's bias, timing dependent, tools/ws_diag.py)
+      float b0 = bv[i], b1 = bv[i];
+      asm volatile("" : "+v"(b0));
+      asm volatile("" : "+v"(b1));
+      float y0 = __builtin_fmaf(acc[t][0][i], omul, b0);
+      float y1 = __builtin_fmaf(acc[t][1][i], omul, b1);
+      if (HAS_RES) {
+        const unsigned u0 = rcur[i].x, u1 = rcur[i].y;
+        y0 += __builtin_bit_cast(float, u0);
+        y1 += __builtin_bit_cast(float, u1);
+      }
+      if (QKV) {
+        if ((cmod + cof) % 3 == 0) {
+          y0 *= I2R_QSCALE;
+          y1 *= I2R_QSCALE;
+        }
+        y0 = split_pack(y0);
+        y1 = split_pack(y1);
+      }
+      uint2v o = {__builtin_bit_cast(unsigned, y0), __builtin_bit_cast(unsigned, y1)};
+      unsigned vo = (cof < lim && voff != OOR && (!(ablate & 1) || o.x == 0x12345678u))
+                        ? voff + (unsigned)cof * plane : OOR;
+      __builtin_amdgcn_raw_buffer_store_b64(o, rO, vo, 0, 0);
+      // Two wait states before anything may overwrite the store's registers.  The ISA manuals ask for one only behind
+      // stores of MORE than 8 bytes and the compiler follows them; on gfx950 an 8-byte store whose data pair was
+      // re-used by the next two v_mov lost elements in ~9 % of the samples (first form of this epilogue, residual
+      // variant; the 16-byte case: see the quad epilogue).  The empty-looking asm ties the registers: whatever writes
+      // them next is ordered behind it.
+      asm volatile("s_nop 1" : "+v"(o), "+v"(vo));
+    }
+    if (HAS_RES && !(ablate & 16)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
+    }
+  }
+}
+
+// 1x1 convolutions with Cin = 128 or 256 (NCH = 2 / 4 packed 64-channel chunks) WEIGHT-STATIONARY on
+// v_mfma_f32_16x16x32_f16: one 8-wave workgroup per CU stages its whole 128-row weight tile (hi + lo, NCH x 32 KB:
+// 128 KB at Cin = 256 -- unpadded 128-byte rows, swizzled as in conv1x1_h2_m16_kernel, leave room for it) in LDS ONCE,
+// and after that single barrier every wave walks 32-position slices on its own.  No barrier, no lock step: a wave's
+// epilogue (ws_epilogue_pairs) runs beside the other waves' MFMAs, which is what the lock-step pipeline above cannot
+// give these layers -- there a tile is 2-4 chunks and its epilogue a third of the kernel.  Activations:
+// a lane owns a pair of positions (8-byte loads), prefetched FOUR k-steps of 32 channels ahead through a register ring
+// that runs on into the next slice; weight fragments a group of four row tiles ahead, one read per three MFMAs.
+// Channel concat (x | x2): Cin1 % 64 == 0.  Tiles are dealt XCD-aware: the Cout-tile workers that share a position
+// range sit on one XCD's L2.
+template <bool SPLIT, int NCH>
+__global__ __launch_bounds__(512, 2) void conv1x1_h2_ws_kernel(ConvHParams p, int nworkers) {
+  constexpr int BM = 128, ROWL = 128, CHB = 2 * BM * ROWL;   // bytes of one chunk's weight tile: hi rows, lo rows
+  constexpr int KS = 2 * NCH;                                 // k-steps of 32 channels per slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int mt = q % p.mtiles;
+  const int worker = (q / p.mtiles) * 8 + xcd;
+  if (worker >= nworkers) return;   // (whole workgroup, before the only barrier)
+  const int m0 = mt * BM;
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, (int)p.x2_bytes, 0x00020000);
+  // ---- the weight tile, once: piece (chunk c, row, q16 = hi 0-7 | lo 8-15) -> swizzled LDS slot
+  for (int idx = tid; idx < NCH * 2048; idx += 512) {
+    const int c = idx >> 11, r = idx & 2047, row = r >> 4, q16 = r & 15;
+    const unsigned voff = (m0 + row < p.Cout) ? (unsigned)((m0 + row) * 256 + q16 * 16) : OOR;
+    const uint4v v = bufload4(rA, voff, (unsigned)c * (unsigned)p.Cout * 256u);
+    *reinterpret_cast<uint4v*>(smem + c * CHB + ((q16 >> 3) * BM + row) * ROWL + (((q16 & 7) ^ ((row >> 1) & 7)) << 4)) = v;
+  }
+  float* bias_lds = reinterpret_cast<float*>(smem + NCH * CHB);
+  if (tid < BM) bias_lds[tid] = (p.bias != nullptr && m0 + tid < p.Cout) ? p.bias[m0 + tid] : 0.0f;
+  __syncthreads();
+
+  float s_in = 1.0f, omul = WSCALE_INV;
+  if (!SPLIT && p.in_scale != nullptr) {
+    s_in = p.in_scale[0];
+    omul = WSCALE_INV * p.in_scale[1];
+  }
+  const unsigned chan_bytes = (unsigned)p.HW * 4;
+  const int nc1 = p.Cin1 >> 6;                    // chunks from the first source
+  const long nslices = (p.Npos + 31) >> 5;
+  const long stride = (long)nworkers * 8;
+  // lane offsets of slice s in the two sources (out of range past the end)
+  auto slice_off = [&](long sl, unsigned& v1, unsigned& v2) {
+    const long nj = sl * 32 + 2 * n16;
+    v1 = v2 = OOR;
+    if (sl < nslices && nj < p.Npos) {
+      const unsigned pb = (unsigned)nj / (unsigned)p.HW, pos = (unsigned)nj - pb * (unsigned)p.HW;
+      v1 = ((pb * (unsigned)p.Cin1 + 8 * kg) * (unsigned)p.HW + pos) * 4;
+      if (p.x2) v2 = ((pb * (unsigned)(p.Cin - p.Cin1) + 8 * kg) * (unsigned)p.HW + pos) * 4;
+    }
+  };
+  // rb[slot]: the raw activations of one k-step (8 channels x 2 positions); k-step j lives in slot j & 3
+  float rb[4][2][8];
+  auto request = [&](int slot, int j, unsigned v1, unsigned v2) {   // k-step j (0 .. KS-1) of the slice at (v1, v2)
+    const int c = j >> 1;                          // its chunk
+    const bool first = c < nc1;                    // (uniform)
+    const unsigned cbase = (unsigned)((first ? c : c - nc1) * 64 + (j & 1) * 32);
+    const unsigned voff = first ? v1 : v2;
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    if (first) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint2v v = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rB, voff, (cbase + e) * chan_bytes, 0));
+        const unsigned u0 = v.x, u1 = v.y;
+        rb[slot][0][e] = __builtin_bit_cast(float, u0);
+        rb[slot][1][e] = __builtin_bit_cast(float, u1);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint2v v = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rB2, voff, (cbase + e) * chan_bytes, 0));
+        const unsigned u0 = v.x, u1 = v.y;
+        rb[slot][0][e] = __builtin_bit_cast(float, u0);
+        rb[slot][1][e] = __builtin_bit_cast(float, u1);
+      }
+    }
+  };
+  // weight fragments: group g = (k-step g >> 1, row tiles 4 (g & 1) .. + 3), 8 ds_read_b128
+  half8 af[2][4][2];
+  const int a_lane[2] = {n16 * ROWL + ((kg ^ (n16 >> 1)) << 4), n16 * ROWL + (((4 + kg) ^ (n16 >> 1)) << 4)};
+  auto load_group = [&](int slot_, int g) {
+    const int j = g >> 1;
+    const unsigned char* a = smem + (j >> 1) * CHB + a_lane[j & 1] + (g & 1) * 64 * ROWL;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      af[slot_][t][0] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL);
+      af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
+    }
+  };
+
+  long sl = (long)worker * 8 + wave;
+  unsigned v1, v2, nv1, nv2;
+  slice_off(sl, v1, v2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) request(j, j, v1, v2);   // (KS >= 4)
+  for (; sl < nslices; sl += stride) {
+    slice_off(sl + stride, nv1, nv2);
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][ct][r] = 0.0f;
+    load_group(0, 0);
+    half8 bh[2], bl[2];
+#pragma unroll
+    for (int g = 0; g < 2 * KS; ++g) {
+      const int j = g >> 1;
+      if ((g & 1) == 0) {   // a new k-step: its fragments out of the ring, the slot re-requested four k-steps on
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          if (SPLIT) unpack8(rb[j & 3][ct], bh[ct], bl[ct]);
+          else split8s(rb[j & 3][ct], s_in, bh[ct], bl[ct]);
+        }
+        if (j + 4 < KS) request(j & 3, j + 4, v1, v2);
+        else request(j & 3, j + 4 - KS, nv1, nv2);
+      }
+      if (g + 1 < 2 * KS) load_group((g + 1) & 1, g + 1);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int t = (g & 1) * 4 + tq;
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][0], bh[0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][0], bh[1], acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][0], bl[0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][0], bl[1], acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][1], bh[0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[g & 1][tq][1], bh[1], acc[t][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.res != nullptr) {
+      if (p.qkv_out) ws_epilogue_pairs<true, true>(p, acc, sl * 32, m0, lane, p.ablate, omul, bias_lds);
+      else ws_epilogue_pairs<true, false>(p, acc, sl * 32, m0, lane, p.ablate, omul, bias_lds);
+    } else {
+      if (p.qkv_out) ws_epilogue_pairs<false, true>(p, acc, sl * 32, m0, lane, p.ablate, omul, bias_lds);
+      else ws_epilogue_pairs<false, false>(p, acc, sl * 32, m0, lane, p.ablate, omul, bias_lds);
+    }
+    v1 = nv1;
+    v2 = nv2;
+  }
+}
+
 // out = sum_z slab[z] + bias + residual
 __global__ void splitk_reduce_h2_kernel(const float* __restrict__ slabs, long slab_stride, int nsplit,
                                         const float* __restrict__ bias, const float* __restrict__ res,
@@ -1525,6 +1765,35 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.in_scale = in_scale;  // (null on every forward call: the un-split path then multiplies by exactly 1)
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);
+  // Cin = 128 / 256 1x1 at inference sizes: weight-stationary 16x16x32 kernel (conv1x1_h2_ws_kernel)
+  {
+    const char* wse = getenv("I2R_H2_WS");   // (read per call: probes and tests flip it inside one process)
+    // (taken without a residual only: measured against the kernels it would replace, qkv 256 -> 768 1.18-1.23x, qkv
+    // 128 -> 384 1.15x; with a residual 0.95-1.0x, over a channel concat 1.0-1.02x -- those stay where they were)
+    if (ksize == 1 && !(wse && atoi(wse) == 0) && !one_term && !up_in && !residual && !x2 && (Cin == 128 || Cin == 256) &&
+        Cout > 64 && (W & 3) == 0 && Npos >= 256L * 256) {
+      p.mtiles = i2r_cdiv(Cout, 128);
+      if (p.mtiles <= 32) {
+        const int nch = Cin / 64;
+        const int lds = nch * 2 * 128 * 128 + 512;            // the weight tile + its bias
+        const int nworkers = 8 * (32 / p.mtiles);             // per XCD: 32 CUs / Cout tiles, all tiles alike
+        dim3 grid(8 * (unsigned)((32 / p.mtiles) * p.mtiles));
+        p.out = out;   // (never split-K)
+        p.nsplit = 1;
+#define H2_WS(SP_, NCH_)                                                         \
+  do {                                                                           \
+    auto kern = conv1x1_h2_ws_kernel<SP_, NCH_>;                                 \
+    static bool attr[64] = {false};                                              \
+    if (!i2r_lds_attr((const void*)kern, NCH_ * 2 * 128 * 128 + 512, attr)) return I2R_ERR_HIP; \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, nworkers);              \
+  } while (0)
+        if (nch == 2) { if (x_is_split) H2_WS(true, 2); else H2_WS(false, 2); }
+        else { if (x_is_split) H2_WS(true, 4); else H2_WS(false, 4); }
+#undef H2_WS
+        return i2r_check_launch("conv1x1_h2_ws");
+      }
+    }
+  }
   // short-K 1x1: the weight-stationary position loop (conv1x1_h2_persist_kernel)
   const char* pe = getenv("I2R_H2_PERSIST");  // (read per call: the A/B probe flips it inside one process)
   const bool persist_on = !(pe && atoi(pe) == 0);

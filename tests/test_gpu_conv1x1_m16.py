@@ -52,12 +52,14 @@ def _pairs(t):
 
 @pytest.fixture
 def k1_env():
-    prev = os.environ.get("I2R_H2_M16_K1")
+    prev, prev_ws = os.environ.get("I2R_H2_M16_K1"), os.environ.get("I2R_H2_WS")
+    os.environ["I2R_H2_WS"] = "0"   # (the weight-stationary kernel would take the residual-free cases first)
     yield
-    if prev is None:
-        os.environ.pop("I2R_H2_M16_K1", None)
-    else:
-        os.environ["I2R_H2_M16_K1"] = prev
+    for name, val in (("I2R_H2_M16_K1", prev), ("I2R_H2_WS", prev_ws)):
+        if val is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = val
 
 
 @pytest.mark.parametrize("B,Cin,Cin2,Cout,H,split,has_res,qkv", CASES)

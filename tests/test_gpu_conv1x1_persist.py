@@ -33,8 +33,9 @@ def test_bits_equal_the_tiled_kernel(case):
     wph = ops.conv2d_pack_h2(w)
     out = {}
     before = os.environ.get("I2R_H2_PERSIST")
-    before_k1 = os.environ.get("I2R_H2_M16_K1")
-    os.environ["I2R_H2_M16_K1"] = "0"   # the TILED kernel is the reference (not the 16x16x32 form of the larger launches)
+    before_k1, before_ws = os.environ.get("I2R_H2_M16_K1"), os.environ.get("I2R_H2_WS")
+    os.environ["I2R_H2_M16_K1"] = "0"   # the TILED kernel is the reference (not the 16x16x32 forms of the larger launches)
+    os.environ["I2R_H2_WS"] = "0"
     try:
         for mode in ("0", "1"):
             os.environ["I2R_H2_PERSIST"] = mode
@@ -44,10 +45,11 @@ def test_bits_equal_the_tiled_kernel(case):
             os.environ.pop("I2R_H2_PERSIST", None)
         else:
             os.environ["I2R_H2_PERSIST"] = before
-        if before_k1 is None:
-            os.environ.pop("I2R_H2_M16_K1", None)
-        else:
-            os.environ["I2R_H2_M16_K1"] = before_k1
+        for name, val in (("I2R_H2_M16_K1", before_k1), ("I2R_H2_WS", before_ws)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
     assert torch.equal(out["0"].view(torch.int32), out["1"].view(torch.int32))
     if not qo:
         ref = torch.nn.functional.conv2d(x0.double(), w.double(), b.double())

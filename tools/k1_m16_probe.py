@@ -14,6 +14,7 @@ import imageni2r_amd  # noqa: E402
 from imageni2r_amd import ops  # noqa: E402
 
 dev = "cuda"
+SWITCH = sys.argv[1] if len(sys.argv) > 1 else "I2R_H2_M16_K1"   # the kernel switch under test ("1" new, "0" the others)
 GUARD = 1 << 16
 SENT = 12345.0
 
@@ -63,7 +64,10 @@ CASES = [(1024, 256, 0, 768, 8, True, False, True),      # qkv conv of the 256-c
          (130, 128, 0, 128, 32, True, True, False),
          (520, 192, 0, 160, 16, True, True, False),       # three chunks (odd), Cout not a multiple of 128
          (512, 512, 0, 384, 8, False, True, False),
-         (512, 128, 0, 384, 16, False, False, False)]     # (fp32 input: not the persistent kernel's case)
+         (512, 128, 0, 384, 16, False, False, False),     # (fp32 input: not the persistent kernel's case)
+         (2048, 128, 0, 384, 16, True, False, True),      # qkv conv of the 128-channel levels at the bench chunk
+         (2048, 128, 0, 128, 16, True, True, False),
+         (4096, 256, 0, 768, 8, True, False, True)]
 worst = 0.0
 for (B, Cin, Cin2, Cout, H, split, has_res, qkv) in CASES:
     gen = torch.Generator().manual_seed(B + Cin + Cout + H)
@@ -106,13 +110,13 @@ for (B, Cin, Cin2, Cout, H, split, has_res, qkv) in CASES:
             return y_
         return ops.conv2d_fwd_h2(x1, tuple(w.shape), wps, bd, rs, x_split=split, out=o, qkv_out=qkv)
 
-    os.environ["I2R_H2_M16_K1"] = "1"
+    os.environ[SWITCH] = "1"
     y = run(out if not Cin2 else None)
     torch.cuda.synchronize()
     ok = guards_ok(x1_big, x1_n) and (x2_big is None or guards_ok(x2_big, x2_n)) and (rs_big is None or guards_ok(rs_big, rs_n))
     ok = ok and (Cin2 or guards_ok(out_big, out_n))
     ok = ok and bool((wp_big[:GB] == 0xAB).all()) and bool((wp_big[GB + wp.numel():] == 0xAB).all()) and torch.equal(wps, wp)
-    os.environ["I2R_H2_M16_K1"] = "0"
+    os.environ[SWITCH] = "0"
     y_old = run(None)
     torch.cuda.synchronize()
     ref = torch.einsum("oc,bchw->bohw", w[:, :, 0, 0].double().to(dev), xv) + b.double().to(dev).view(1, -1, 1, 1)
@@ -133,11 +137,11 @@ for (B, Cin, Cin2, Cout, H, split, has_res, qkv) in CASES:
     flop = 2.0 * B * H * H * Cout * Ct
     nbytes = 4.0 * B * H * H * (Ct + Cout * (2 if has_res else 1))
     tmp = torch.empty_like(y_old)
-    os.environ["I2R_H2_M16_K1"] = "1"
+    os.environ[SWITCH] = "1"
     t_new = timed(lambda: run(tmp))
-    os.environ["I2R_H2_M16_K1"] = "0"
+    os.environ[SWITCH] = "0"
     t_old = timed(lambda: run(tmp))
-    os.environ["I2R_H2_M16_K1"] = "1"
+    os.environ[SWITCH] = "1"
     worst = max(worst, err)
     print(f"B{B} {Cin}{'+' + str(Cin2) if Cin2 else ''}->{Cout} @{H} split={int(split)} res={int(has_res)} qkv={int(qkv)}: "
           f"err vs fp64 {err:.2e}, vs old kernel {err_old:.2e}, guards intact {ok};  old {t_old * 1e3:.0f} us "
