@@ -19,7 +19,8 @@ import sys
 
 FAMILIES = {  # family -> (kernel-name substrings, FETCH_SIZE correction factor)
     "conv_fwd_h2_k3": (("conv_fwd_h2_kernel<3", "conv3x3_h2_m16_kernel"), 1.0),
-    "conv_fwd_h2_k1": (("conv_fwd_h2_kernel<1", "conv1x1_h2_persist_kernel"), 1.0),
+    "conv_fwd_h2_k1": (("conv_fwd_h2_kernel<1", "conv1x1_h2_persist_kernel", "conv1x1_h2_m16_kernel",
+                        "conv1x1_h2_ws_kernel"), 1.0),
     "attention_fwd_h2": (("attn_fwd_h2_kernel",), 1.0),
     "groupnorm_fwd": (("gn_fwd_reg_kernel", "gn_fwd_small_kernel", "gn_cat_fwd", "gn_fwd_cat", "groupnorm_fwd_kernel"), 2.0),
 }
