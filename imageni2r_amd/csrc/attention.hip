@@ -97,14 +97,104 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(const float* __restri
 // contiguous run of 192*T floats and its output one of 64*T: both are walked linearly (consecutive lanes, consecutive
 // addresses), and LDS is sized by TM so that the 2x2 / 4x4 levels keep 10+ workgroups per CU in flight -- at batch
 // 4096 these launches stream 270 MB each and were latency-bound at 1.2 TB/s with the fixed 32-wide layout.
+// T a multiple of 4 (the 2x2 and 4x4 levels): 16-byte global accesses and four outputs per thread and inner step (two
+// LDS reads per four multiply-adds instead of eight).  Every element is still the same sum in the same order as in the
+// general form below (the 1/8 on k is a power of two, so applying it while staging changes no bit), so the results are
+// the same.  Scores are kept TRANSPOSED (St[key][query]) so that the second product reads four queries of a key with
+// one access.  TC: T when it is known at compile time (all loops unroll, the twelve loads of a thread are in flight
+// together), 0 otherwise.
+template <int TM, int TC>
+__device__ __forceinline__ void attn_small_vec(const float* __restrict__ base, float* __restrict__ ob, float* __restrict__ lse_row,
+                                               float (*QKV)[HD * TM], float* S, int Trt, int tid) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int T = TC ? TC : Trt;
+  const f4* base4 = reinterpret_cast<const f4*>(base);
+  const int T4 = T >> 2;
+  constexpr int SP = TM + 4;
+  constexpr int UNR = TC ? 64 : 1;   // (full unrolling when the trip counts are constants, none otherwise)
+#pragma unroll UNR
+  for (int it = 0; it < (3 * HD * T4 + 63) / 64; ++it) {
+    const int i4 = tid + 64 * it;
+    if (i4 >= 3 * HD * T4) break;
+    const int row = i4 / T4, t = (i4 - row * T4) * 4;
+    const int d = row / 3, sel = row - 3 * d;
+    f4 v = base4[i4];
+    if (sel == 1) v *= 0.125f;
+    *reinterpret_cast<f4*>(&QKV[sel][d * TM + t]) = v;
+  }
+  __syncthreads();
+  const float* Q = QKV[0];
+  const float* K = QKV[1];
+  const float* V = QKV[2];
+#pragma unroll UNR
+  for (int it = 0; it < (T * T4 + 63) / 64; ++it) {
+    const int idx = tid + 64 * it;
+    if (idx >= T * T4) break;
+    const int qi = idx / T4, ki = (idx - qi * T4) * 4;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 16
+    for (int d = 0; d < HD; ++d) {
+      const float q = Q[d * TM + qi];
+      const f4 k4 = *reinterpret_cast<const f4*>(&K[d * TM + ki]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += q * k4[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[(ki + j) * SP + qi] = acc[j];
+  }
+  __syncthreads();
+  if (tid < T) {   // softmax over the keys of query `tid` (a column of St)
+    float m = S[tid];
+#pragma unroll UNR
+    for (int k = 1; k < T; ++k) m = fmaxf(m, S[k * SP + tid]);
+    float sum = 0.0f;
+#pragma unroll UNR
+    for (int k = 0; k < T; ++k) {
+      float e = expf(S[k * SP + tid] - m);
+      S[k * SP + tid] = e;
+      sum += e;
+    }
+    float inv = 1.0f / sum;
+#pragma unroll UNR
+    for (int k = 0; k < T; ++k) S[k * SP + tid] *= inv;
+    if (lse_row) lse_row[tid] = m + logf(sum);
+  }
+  __syncthreads();
+#pragma unroll UNR
+  for (int it = 0; it < (HD * T4 + 63) / 64; ++it) {
+    const int idx = tid + 64 * it;
+    if (idx >= HD * T4) break;
+    const int c = idx / T4, qi = (idx - c * T4) * 4;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll UNR
+    for (int k = 0; k < T; ++k) {
+      const float v = V[c * TM + k];
+      const f4 p4 = *reinterpret_cast<const f4*>(&S[k * SP + qi]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += p4[j] * v;
+    }
+    *reinterpret_cast<f4*>(ob + c * T + qi) = acc;
+  }
+}
+
 template <int TM>
 __global__ __launch_bounds__(64) void attn_fwd_small_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             float* __restrict__ lse, int heads, int T) {
-  __shared__ float QKV[3][HD * TM], S[TM * (TM + 1)];
+  __shared__ __attribute__((aligned(16))) float QKV[3][HD * TM];
+  __shared__ __attribute__((aligned(16))) float S[TM * (TM + 4)];
   const int tid = threadIdx.x;
   const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
   const int C = heads * HD;
   const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;  // row 3 d + s (s: q, k, v), T floats each
+  float* ob = out + ((long)b * C + (long)hd * HD) * T;  // (channel, query) row-major: idx = c * T + qi
+  if (TM <= 16 && T == TM) {
+    attn_small_vec<TM, (TM <= 16 ? TM : 0)>(base, ob, lse ? lse + (long)bh * T : nullptr, QKV, S, T, tid);
+    return;
+  }
+  if ((T & 3) == 0) {
+    attn_small_vec<TM, 0>(base, ob, lse ? lse + (long)bh * T : nullptr, QKV, S, T, tid);
+    return;
+  }
   for (int idx = tid; idx < 3 * HD * T; idx += 64) {
     int row = idx / T, t = idx - row * T;
     int d = row / 3, sel = row - 3 * d;
@@ -136,7 +226,6 @@ __global__ __launch_bounds__(64) void attn_fwd_small_kernel(const float* __restr
     if (lse) lse[(long)bh * T + tid] = m + logf(sum);
   }
   __syncthreads();
-  float* ob = out + ((long)b * C + (long)hd * HD) * T;  // (channel, query) row-major: idx = c * T + qi
   for (int idx = tid; idx < HD * T; idx += 64) {
     int c = idx / T, qi = idx - c * T;
     float acc = 0.0f;
@@ -579,10 +668,12 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(const float* __res
     }
 }
 
-// T <= 32: one 64-thread block per (sample, head), everything in LDS; recomputes the softmax itself.
-__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv,
-                                                            const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, int heads, int T) {
+// T <= 32: one 256-thread block per (sample, head), everything in LDS; recomputes the softmax itself.  (Four waves,
+// not one: at the training batch there are only B * heads = 128 workgroups on 256 CUs, so the launch is as long as ONE
+// workgroup's chain of dependent LDS loops -- 23 us with one wave; every element is the same sum in the same order.)
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ qkv,
+                                                             const float* __restrict__ dout,
+                                                             float* __restrict__ dqkv, int heads, int T) {
   __shared__ float Q[HD * 32], K[HD * 32], V[HD * 32], dA[HD * 32], P[32 * 33], dS[32 * 33];
   const int tid = threadIdx.x;
   const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
@@ -590,7 +681,7 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restr
   const float* base = qkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
   float* dbase = dqkv + ((long)b * 3 * C + (long)hd * 3 * HD) * T;
   const float* dab = dout + ((long)b * C + (long)hd * HD) * T;
-  for (int idx = tid; idx < HD * T; idx += 64) {
+  for (int idx = tid; idx < HD * T; idx += 256) {
     int d = idx / T, t = idx % T;
     Q[d * 32 + t] = base[(long)(3 * d + 0) * T + t];
     K[d * 32 + t] = base[(long)(3 * d + 1) * T + t];
@@ -598,9 +689,10 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restr
     dA[d * 32 + t] = dab[(long)d * T + t];
   }
   __syncthreads();
-  for (int idx = tid; idx < T * T; idx += 64) {
+  for (int idx = tid; idx < T * T; idx += 256) {
     int qi = idx / T, ki = idx % T;
     float acc = 0.0f, dp = 0.0f;
+#pragma unroll 8
     for (int d = 0; d < HD; ++d) {
       acc += Q[d * 32 + qi] * (K[d * 32 + ki] * 0.125f);
       dp += dA[d * 32 + qi] * V[d * 32 + ki];
@@ -627,20 +719,21 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restr
     for (int k = 0; k < T; ++k) dS[tid * 33 + k] = P[tid * 33 + k] * (dS[tid * 33 + k] - del);
   }
   __syncthreads();
-  // thread = channel / head-dim index
-  for (int k = 0; k < T; ++k) {
+  // lane = channel (head-dim index), wave = every fourth key / query
+  const int c = tid & 63, part = tid >> 6;
+  for (int k = part; k < T; k += 4) {
     float dv = 0.0f, dk = 0.0f;
     for (int q = 0; q < T; ++q) {
-      dv += dA[tid * 32 + q] * P[q * 33 + k];
-      dk += dS[q * 33 + k] * Q[tid * 32 + q];
+      dv += dA[c * 32 + q] * P[q * 33 + k];
+      dk += dS[q * 33 + k] * Q[c * 32 + q];
     }
-    dbase[(long)(3 * tid + 1) * T + k] = dk * 0.125f;
-    dbase[(long)(3 * tid + 2) * T + k] = dv;
+    dbase[(long)(3 * c + 1) * T + k] = dk * 0.125f;
+    dbase[(long)(3 * c + 2) * T + k] = dv;
   }
-  for (int q = 0; q < T; ++q) {
+  for (int q = part; q < T; q += 4) {
     float dq = 0.0f;
-    for (int k = 0; k < T; ++k) dq += dS[q * 33 + k] * K[tid * 32 + k];
-    dbase[(long)(3 * tid + 0) * T + q] = dq * 0.125f;
+    for (int k = 0; k < T; ++k) dq += dS[q * 33 + k] * K[c * 32 + k];
+    dbase[(long)(3 * c + 0) * T + q] = dq * 0.125f;
   }
 }
 
@@ -649,7 +742,7 @@ extern "C" int i2r_attention_bwd_f32(const float* qkv, const float* out, const f
   I2R_REQUIRE(qkv && dout && dqkv && B > 0 && heads > 0 && T > 0, "attention_bwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   if (T <= 32) {
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(64), 0, s, qkv, dout, dqkv, heads, T);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(256), 0, s, qkv, dout, dqkv, heads, T);
     return i2r_check_launch("attention_bwd");
   }
   I2R_REQUIRE(T % 32 == 0, "attention_bwd: T=%d must be <= 32 or a multiple of 32", T);
