@@ -260,7 +260,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnP p) {
   const long wg = (long)b * p.G + g;
   const int cpg = p.C / p.G, n = cpg * p.HW;
   __shared__ float gb_lds[2][64];
-  const bool gb_in_lds = SLOTS > 1 && p.gb_lds && p.dg_acc && cpg <= 64;   // (uniform over the workgroup)
+  // The whole-workgroup forms (SLOTS = 1) go through LDS too: the cpg channel sums then leave in ONE atomic
+  // instruction of cpg adjacent lanes instead of one per channel from its own wave -- what queues on a line are
+  // requests, not lanes (32 x 128 x 16 x 16: 19.3 -> see tools/r3_gn_bwd_prof.sh).
+  const bool gb_in_lds = p.gb_lds && p.dg_acc && cpg <= 64;   // (uniform over the workgroup)
   if (gb_in_lds) {
     if (threadIdx.x < 128) (&gb_lds[0][0])[threadIdx.x] = 0.0f;
     __syncthreads();

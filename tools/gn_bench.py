@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused GroupNorm kernels (achieved HBM GB/s; also the target of rocprofv3 --pmc passes).
 
-    python tools/gn_bench.py [--batch 1024] [--iters 20] [--bwd]
-Shapes = the GroupNorm sites of the B1/C network: (C, H)."""
+    python tools/gn_bench.py [--batch 1024] [--iters 20] [--bwd [--acc] [--add]]
+--acc: dgamma / dbeta accumulated into given slots with atomics (the training step's form) instead of per-sample
+partials + a row reduction; --add: with the bypass gradient added to dx.  At small batches the loop is host-bound: read
+the kernel times from `rocprofv3 --kernel-trace --stats`.  Shapes = the GroupNorm sites of the B1/C network: (C, H)."""
 import argparse
 import os
 import sys
@@ -16,6 +18,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--acc", action="store_true")
+ap.add_argument("--add", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
 for (C, H) in [(128, 16), (256, 16), (384, 16), (256, 8), (512, 8), (256, 4), (512, 2), (1024, 2)]:
@@ -26,8 +30,11 @@ for (C, H) in [(128, 16), (256, 16), (384, 16), (256, 8), (512, 8), (256, 4), (5
     dy = torch.randn_like(x)
     if a.bwd:
         _, mean, rstd = ops.groupnorm_fwd(x, w, b, 32, 1e-5, ss=ss, act=True, save_stats=True)
-        fn = lambda: ops.groupnorm_bwd(x, w, b, ss, mean, rstd, dy, 32, True)
-        bytes_per_elem = 12
+        dg, db = (torch.zeros(C, device=dev), torch.zeros(C, device=dev)) if a.acc else (None, None)
+        ops.set_slots_zeroed(a.acc)
+        addt = torch.randn_like(x) if a.add else None
+        fn = lambda: ops.groupnorm_bwd(x, w, b, ss, mean, rstd, dy, 32, True, dgamma=dg, dbeta=db, add=addt)
+        bytes_per_elem = 16 if a.add else 12
     else:
         fn = lambda: ops.groupnorm_fwd(x, w, b, 32, 1e-5, ss=ss, act=True, split_out=True)
         bytes_per_elem = 8

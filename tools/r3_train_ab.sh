@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU-box script: B1 / D / A train step with the GroupNorm backward's dgamma / dbeta sums pre-reduced over the samples
-# of a workgroup in LDS (I2R_GN_BWD_LDS, default on) and without, alternating on one box.
+# GPU-box script: B1 / D / A train step with the GroupNorm backward's dgamma / dbeta sums gathered in LDS per workgroup
+# (I2R_GN_BWD_LDS, default on) and without, alternating on one box.
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r3_train_ab.log
