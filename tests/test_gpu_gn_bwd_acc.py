@@ -4,7 +4,8 @@
 in LDS and leave as one atomic request per workgroup.  Checked against the per-sample-partials form + ordered row
 reduction (i2r_groupnorm_bwd_f32 + i2r_reduce_rows_f32): dx and dscale / dshift bit for bit, the parameter gradients to
 2e-6 of their largest value; twice in a row into the same slots, and with the switch that puts one atomic per sample
-and channel back (I2R_GN_BWD_LDS=0)."""
+and channel back (I2R_GN_BWD_LDS=0).  1x1 images take gn_bwd_hw1_kernel (one lane per channel); checked against the
+generic kernel it replaces as well (I2R_GN_HW1=0)."""
 import os
 
 import pytest
@@ -15,12 +16,13 @@ DEV = "cuda"
 
 # (B, C, H): kernel forms <256,1> <256,2> <256,4> <256,8> (few groups) | <64,4> (many groups) | <64,2> <32,1> <16,1>
 CASES = [(32, 128, 16), (32, 256, 16), (7, 384, 16), (3, 256, 32), (1, 128, 16), (80, 128, 16), (32, 256, 8), (33, 256, 4),
-         (32, 512, 2), (5, 64, 8)]
+         (32, 512, 2), (5, 64, 8),
+         (128, 512, 1), (5, 1024, 1), (33, 256, 1), (3, 2048, 1)]   # 1x1 images: gn_bwd_hw1_kernel<16|32|64>
 
 
 @pytest.fixture
 def gn_env():
-    names = ("I2R_GN_BWD_LDS",)
+    names = ("I2R_GN_BWD_LDS", "I2R_GN_HW1")
     prev = {n: os.environ.get(n) for n in names}
     yield
     for n, v in prev.items():
@@ -60,5 +62,52 @@ def test_gn_bwd_slot_accumulation_against_the_partials_form(gn_env, B, C, H, wit
             for got, ref in ((og, dg_ref), (ob, db_ref)):
                 err = float((got - ref).abs().max() / ref.abs().max())
                 assert err < 2e-6, (lds, err)
+        if H == 1:   # against the generic kernel (one wave per sample and group), which the 1x1 form replaces
+            os.environ["I2R_GN_HW1"] = "0"
+            ops.set_slots_zeroed(False)
+            dx_g, dg_g, db_g, dss_g = ops.groupnorm_bwd(x, w, b, ss, mean, rstd, dy, 32, True, add=add)
+            for got, ref in ((dx_ref, dx_g), (dg_ref, dg_g), (db_ref, db_g)) + (((dss_ref, dss_g),) if with_ss else ()):
+                err = float((got - ref).abs().max() / ref.abs().max())
+                assert err < 2e-6, err
     finally:
         ops.set_slots_zeroed(prev)
+
+
+@pytest.mark.parametrize("B,C", [(4096, 512), (130, 1024), (7, 256), (3, 2048), (33, 96)])
+@pytest.mark.parametrize("variant", ["plain", "ss_act", "ss1_act_split", "act_drop"])
+def test_gn_fwd_on_1x1_images_against_the_generic_kernel_and_fp64(gn_env, B, C, variant):
+    """gn_fwd_hw1_kernel<16|32|64> (one lane per channel; C = 96: 3 channels per group, 13 idle lanes per slot): output,
+    mean and rstd against the generic kernel (I2R_GN_HW1=0; 2e-6, dropped elements at the same places) and the plain
+    form against fp64 group normalisation."""
+    from imageni2r_amd import ops
+    gen = torch.Generator().manual_seed(B + C)
+    x = (torch.randn(B, C, 1, 1, generator=gen) * 1.3 + 0.2).to(DEV)
+    w, b = torch.randn(C, generator=gen).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    kw = {}
+    if variant == "ss_act":
+        kw = dict(ss=(torch.randn(B, 2 * C, generator=gen) * 0.3).to(DEV), act=True, save_stats=True)
+    elif variant == "ss1_act_split":
+        kw = dict(ss=(torch.randn(1, 2 * C, generator=gen) * 0.3).to(DEV), act=True, split_out=True)
+    elif variant == "act_drop":
+        kw = dict(act=True, drop_p=0.25, seed=1234, offset=77, save_stats=True)
+    outs = {}
+    for sw in ("1", "0"):
+        os.environ["I2R_GN_HW1"] = sw
+        outs[sw] = ops.groupnorm_fwd(x, w, b, 32, 1e-5, **kw)
+    torch.cuda.synchronize()
+    y1, y0 = outs["1"][0], outs["0"][0]
+    if variant == "ss1_act_split":   # split pairs: compare what they decode to
+        dec = lambda t: ((t.view(torch.int32) & 0xFFFF).to(torch.int16).view(torch.float16).double()   # noqa: E731
+                         + ((t.view(torch.int32) >> 16) & 0xFFFF).to(torch.int16).view(torch.float16).double())
+        y1, y0 = dec(y1), dec(y0)
+    assert float((y1 - y0).abs().max() / y0.abs().max()) < 2e-6
+    if variant == "act_drop":
+        assert torch.equal(y1 == 0, y0 == 0) and 0.15 < float((y1 == 0).float().mean()) < 0.35
+    if kw.get("save_stats"):
+        for i in (1, 2):
+            assert float((outs["1"][i] - outs["0"][i]).abs().max() / outs["0"][i].abs().max()) < 2e-6
+    if variant == "plain":
+        xd = x.double().view(B, 32, C // 32)
+        ref = ((xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5)).view(B, C, 1, 1)
+        ref = ref * w.double().view(1, C, 1, 1) + b.double().view(1, C, 1, 1)
+        assert float((y1.double() - ref).abs().max() / ref.abs().max()) < 2e-6
