@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 //     this kernel: 16 loads, 32 DPP moves -- the pair form measured +3 to +10 % on every probe shape).  Image rows of
 //     32 need no border select at all (the row shift's zero fill IS the border); narrower rows mask two taps.
 // Taken for W in {2, 4, 8, 16, 32}, Cin % 32 == 0, Cout > 64, >= 256 tiles of 256 positions x 128 channels, never
-// split-K (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 2 = image rows of 32, 0 = narrower ones.
+// split-K (one 8-wave workgroup per CU: 250 registers per lane; two weight stages are 96 KB of LDS).  WM: 2 = image rows of 32, 1 = rows of 2 (2x2 images), 0 = the widths between.
 #ifndef M16_ABL
 #define M16_ABL 0  /* tuning builds only (tools/r3_m16_ablate.sh): 1 no fragment reads from LDS, 2 no fragment build,
                       4 no weight staging, 8 no global loads in the loop, 16 no barrier -- results are then garbage */
@@ -750,6 +750,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
     for (int e = 0; e < 4; ++e) {
       // left of the even position: the odd position one lane down (0 into a 16-lane row's first lane: with image rows
       // of 32 that IS the border; narrower rows also end inside the 16 lanes)
+      if (WM == 1) {   // image rows of 2: a pair IS a row -- the even position has no left, the odd one no right
+        lh[e] = ll[e] = rh[e] = rl[e] = 0u;
+        continue;
+      }
       lh[e] = row_dpp<DPP_ROW_SHR1, true>(0u, ch[1][e]);
       ll[e] = row_dpp<DPP_ROW_SHR1, true>(0u, cl[1][e]);
       rh[e] = row_dpp<DPP_ROW_SHL1, true>(0u, ch[0][e]);
@@ -831,17 +835,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
       af[slot_][t][1] = *reinterpret_cast<const half8*>(a + t * 16 * ROWL + BM * ROWL);
     }
   };
+  // (rows of 2, WM = 1: the left tap of the even column tile and the right tap of the odd one are all padding -- those
+  // MFMAs would add exact zeros and are not issued: 96 instead of 144 per chunk)
   auto mfma_group = [&](int slot_, int g) {
     const int sx = g >> 1;
+    const bool do0 = !(WM == 1 && sx == 0), do1 = !(WM == 1 && sx == 2);
 #pragma unroll
     for (int tq = 0; tq < 4; ++tq) {
       const int t = (g & 1) * 4 + tq;
-      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][0], acc[t][0], 0, 0, 0);
-      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][1], acc[t][1], 0, 0, 0);
-      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][0], acc[t][0], 0, 0, 0);
-      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][1], acc[t][1], 0, 0, 0);
-      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][0], acc[t][0], 0, 0, 0);
-      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][1], acc[t][1], 0, 0, 0);
+      if (do0) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][0], acc[t][0], 0, 0, 0);
+      if (do1) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bh[sx][1], acc[t][1], 0, 0, 0);
+      if (do0) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][0], acc[t][0], 0, 0, 0);
+      if (do1) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][0], bl[sx][1], acc[t][1], 0, 0, 0);
+      if (do0) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][0], acc[t][0], 0, 0, 0);
+      if (do1) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot_][tq][1], bh[sx][1], acc[t][1], 0, 0, 0);
     }
   };
   a_tile(0);
@@ -868,10 +875,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_m16_kernel(ConvHParams p) {
       // instruction stream for ~50 cycles in which no MFMA issues and the matrix pipe runs dry (measured: 12 %)
       if (g < 5) load_group((g + 1) & 1, g + 1, s);
       mfma_group(g & 1, g);
+      if (WM == 1 && (g >> 1) != 1) {   // the 12-MFMA groups: 2, 1, 2, 1, ... MFMAs per fragment read
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1856,8 +1873,11 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   // the large 3x3 layers: the 16x16x32 MFMA form (conv3x3_h2_m16_kernel)
   const char* m16 = getenv("I2R_H2_M16");  // (read per call: A/B probes and tests flip it inside one process)
   static const long m16_mintiles = getenv("I2R_H2_M16_MINTILES") ? atol(getenv("I2R_H2_M16_MINTILES")) : 256;
-  const bool m16_size = (bn == 256 && nsplit == 1) ||
-                        (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128) >= m16_mintiles;
+  // (2x2 images from half that size on: their form of the kernel issues a third fewer MFMAs, and the sampler runs such
+  // launches of a 2048-series half batch -- 128 tiles -- beside the other half's on a second stream)
+  const long m16_tiles = (long)i2r_cdiv(Npos, 256) * i2r_cdiv(Cout, 128);
+  const bool m16_size = (bn == 256 && nsplit == 1) || m16_tiles >= m16_mintiles ||
+                        (W == 2 && H == 2 && 2 * m16_tiles >= m16_mintiles && !getenv("I2R_H2_M16_W2OFF"));
   if (ksize == 3 && !(m16 && atoi(m16) == 0) && !one_term && !x2 && bm == 128 && Cout > 64 && Cout <= 2048 && m16_size &&
       Cin % 32 == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || (W == 2 && H == 2 && !up_in && !up_res)) &&
       !getenv("I2R_H2_NODPP")) {
@@ -1877,6 +1897,7 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   do {                                                 \
     if (W == 32 && up_in) H2_M16(SP_, 2, true);        \
     else if (W == 32) H2_M16(SP_, 2, false);           \
+    else if (W == 2 && !getenv("I2R_H2_M16_W2OFF")) H2_M16(SP_, 1, false); \
     else if (up_in) H2_M16(SP_, 0, true);              \
     else H2_M16(SP_, 0, false);                        \
   } while (0)

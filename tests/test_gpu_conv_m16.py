@@ -28,7 +28,9 @@ CASES = [(512, 128, 128, 16, True, True, False, False),
          (128, 128, 128, 32, True, False, True, False),
          (1024, 256, 256, 8, True, True, True, True),
          (512, 128, 256, 16, False, True, False, False),
-         (8200, 512, 512, 2, True, True, False, False)]
+         (8200, 512, 512, 2, True, True, False, False),
+         (2048, 512, 512, 2, True, True, False, False),    # 2x2 images are taken from 128 tiles on (a half batch)
+         (2050, 1024, 512, 2, True, False, False, False)]
 
 
 def _padded(t):
