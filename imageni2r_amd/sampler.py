@@ -48,7 +48,7 @@ class DiffusionProcess:
         # at every evaluation, and with the pointer-swapped ema_scope the weights it sees sit at the same addresses
         # each time, so the second evaluation replays the first one's graphs
         self._graphs = self.net.__dict__.setdefault("_i2r_sampler_graphs", {})
-        self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big are sampled as two concurrent half-batch graphs (0: off)
+        self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))  # batches at least this big (or of as many positions as that many 16x16 images) are sampled as two concurrent half-batch graphs (0: off)
         self._streams = None
         # fp16 range guard of the f16x2 kernels (DESIGN.md "range contract"): series that come back non-finite are
         # sampled again on the exact fp32 kernels.  One isfinite reduction + host sync per sample() call; 0 = off.
@@ -164,7 +164,12 @@ class DiffusionProcess:
         return out
 
     def _dual(self, m):
-        return bool(self.dual_stream_min) and m >= self.dual_stream_min and m % 2 == 0
+        """Two concurrent half-batch graphs from `dual_stream_min` series on -- or from as many POSITIONS as that many
+        16x16 images have (1024 series of 32x32: shape D at its bench batch, +1.4 %, tools/r3_dual_d.sh)."""
+        if not self.dual_stream_min or m % 2:
+            return False
+        hw = int(self.shape[-1]) * int(self.shape[-2])
+        return m >= self.dual_stream_min or m * hw >= self.dual_stream_min * 512
 
     def _sample_any(self, latents, t_steps, t_host, cap):
         """Series per captured loop never exceed `cap` (every activation of a piece has to stay under the conv kernels'

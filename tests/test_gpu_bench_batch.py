@@ -48,7 +48,9 @@ def test_sampler_at_the_bench_batch_against_the_golden_and_the_small_batch_path(
     xT[0] = d["xT"][0]
     xT[batch - 1] = d["xT"][0]
     proc = DiffusionProcess(args, m.net, (C, S, S))       # default dispatch, as bench.py's sampler_bench builds it:
-    assert proc._dual(batch) == (batch >= 2048)           # B1: two concurrent half-batch graphs; D: one graph
+    assert proc._dual(batch)                              # B1 at 4096 and D at 1024 (a million positions each): two
+                                                          # concurrent half-batch graphs
+    assert not proc._dual(batch // 4) and not proc._dual(batch - 1)
     out = proc.sample(xT)
     assert out.dtype == torch.float64 and tuple(out.shape) == (batch, C, S, S) and bool(torch.isfinite(out).all())
     ref = g[name + "/sample"]
