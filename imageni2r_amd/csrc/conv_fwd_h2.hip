@@ -1785,10 +1785,11 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   // Cin = 128 / 256 1x1 at inference sizes: weight-stationary 16x16x32 kernel (conv1x1_h2_ws_kernel)
   {
     const char* wse = getenv("I2R_H2_WS");   // (read per call: probes and tests flip it inside one process)
+    static const long ws_minpos = getenv("I2R_H2_WS_MINPOS") ? atol(getenv("I2R_H2_WS_MINPOS")) : 128L * 256;   // (65536 until the sampler's half-batch graphs were looked at: +0.8 % on B1, tools/r3_wsmin_ab.sh)
     // (taken without a residual only: measured against the kernels it would replace, qkv 256 -> 768 1.18-1.23x, qkv
     // 128 -> 384 1.15x; with a residual 0.95-1.0x, over a channel concat 1.0-1.02x -- those stay where they were)
     if (ksize == 1 && !(wse && atoi(wse) == 0) && !one_term && !up_in && !residual && !x2 && (Cin == 128 || Cin == 256) &&
-        Cout > 64 && (W & 3) == 0 && Npos >= 256L * 256) {
+        Cout > 64 && (W & 3) == 0 && Npos >= ws_minpos) {
       p.mtiles = i2r_cdiv(Cout, 128);
       if (p.mtiles <= 32) {
         const int nch = Cin / 64;

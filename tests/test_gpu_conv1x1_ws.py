@@ -1,6 +1,6 @@
 """conv1x1_h2_ws_kernel -- the residual-free 1x1 convs with Cin = 128 / 256 (the qkv convs of the attention blocks,
 models/networks.py:181) weight-stationary on v_mfma_f32_16x16x32_f16, decoupled waves, 8-byte pair stores straight from
-the accumulators.  Taken from 65536 positions on.  Checked through the C ABI:
+the accumulators.  Taken from 32768 positions on.  Checked through the C ABI:
 
 * against the fp64 product of the very operands the kernel multiplies, every sample, 5e-6 -- fp32-grade;
 * against the tiled kernel (`I2R_H2_WS=0`, `I2R_H2_M16_K1=0`, `I2R_H2_PERSIST=0`), 2e-6;
@@ -29,7 +29,8 @@ CASES = [(1024, 256, 768, 8, True, True),
          (1024, 256, 200, 8, True, False),
          (300, 128, 130, 16, False, False),
          (70, 128, 384, 32, True, True),
-         (1100, 256, 256, 8, False, False)]
+         (1100, 256, 256, 8, False, False),
+         (2048, 256, 768, 4, True, True)]    # exactly 32768 positions: the smallest launch that takes it
 
 
 @pytest.fixture
