@@ -1884,7 +1884,11 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
       !getenv("I2R_H2_NODPP")) {
     const int lds = 2 * 2 * 128 * (96 * 2) + 8 * 32 * EPI_PITCH * 4 + p.mtiles * 128 * 4;  // stages, patches, bias
     const long per_xcd = (long)((i2r_cdiv(Npos, 256) + 7) / 8) * p.mtiles;  // tile-list entries of one XCD
-    dim3 grid(8 * (unsigned)(per_xcd < 32 ? per_xcd : 32));                // one workgroup per CU
+    // (I2R_H2_M16_CUS: workgroups per XCD, default all 32 CUs -- an experiment switch: fewer leave CUs to a second
+    // stream's memory-bound kernels)
+    static const long m16_cus = getenv("I2R_H2_M16_CUS") ? atol(getenv("I2R_H2_M16_CUS")) : 32;
+    const long cus = m16_cus >= 1 && m16_cus <= 32 ? m16_cus : 32;
+    dim3 grid(8 * (unsigned)(per_xcd < cus ? per_xcd : cus));              // one workgroup per CU
     p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
     p.nsplit = 1;
 #define H2_M16(SP_, WM_, UP_)                                                                                   \
