@@ -98,6 +98,16 @@ class Conv2d(torch.nn.Module):
             self._wph_key = key
         return self._wph
 
+    def packed_weight_h2_center(self):
+        """Split-f16 packed copy of the CENTRE TAP of a 3x3 weight, as a 1x1 weight (same invalidation rule): on a 1x1
+        image the other eight taps only ever meet the zero padding (:68-90 with padding 1)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, ops.pack_epoch())
+        if getattr(self, "_wphc_key", None) != key:
+            self._wphc = ops.conv2d_pack_h2(w.detach()[:, :, 1:2, 1:2].contiguous())
+            self._wphc_key = key
+        return self._wphc
+
     def packed_weight_h2_dgrad(self):
         """Split-f16 packed copy for the data gradient on the f16x2 kernel (same invalidation rule)."""
         w = self.weight
@@ -136,6 +146,13 @@ class Conv2d(torch.nn.Module):
             x = ops.Down2Fn.apply(x)
         if self.weight is not None:
             if not torch.is_grad_enabled() and ops.h2_math():
+                if (self.weight.shape[2] == 3 and x.shape[2] == 1 and x.shape[3] == 1 and not up_res
+                        and os.environ.get("I2R_CENTER_TAP") != "0"):
+                    # a 3x3 conv on a 1x1 image is the 1x1 conv of its centre tap: a ninth of the multiply-adds
+                    wshape = (self.weight.shape[0], self.weight.shape[1], 1, 1)
+                    return ops.conv2d_fwd_h2(ops._c(x), wshape, self.packed_weight_h2_center(), self.bias,
+                                             None if residual is None else ops._c(residual), x_split, out, qkv_out,
+                                             False, False)
                 return ops.conv2d_fwd_h2(ops._c(x), self.weight.shape, self.packed_weight_h2(), self.bias,
                                          None if residual is None else ops._c(residual), x_split, out, qkv_out,
                                          False, up_res)
