@@ -1888,7 +1888,12 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
     // stream's memory-bound kernels)
     static const long m16_cus = getenv("I2R_H2_M16_CUS") ? atol(getenv("I2R_H2_M16_CUS")) : 32;
     const long cus = m16_cus >= 1 && m16_cus <= 32 ? m16_cus : 32;
-    dim3 grid(8 * (unsigned)(per_xcd < cus ? per_xcd : cus));              // one workgroup per CU
+    // (I2R_H2_M16_TPW: at least this many tiles per workgroup, default 1 -- an experiment switch: short launches on
+    // fewer CUs, each workgroup pipelining over several tiles, the rest of the chip left to the other stream)
+    static const long m16_tpw = getenv("I2R_H2_M16_TPW") ? atol(getenv("I2R_H2_M16_TPW")) : 1;
+    long wgs = per_xcd < cus ? per_xcd : cus;
+    if (m16_tpw > 1 && wgs * m16_tpw > per_xcd) wgs = per_xcd / m16_tpw > 0 ? per_xcd / m16_tpw : 1;
+    dim3 grid(8 * (unsigned)wgs);                                          // one workgroup per CU
     p.out = out;  // (never split-K: a plan made for the 128-position tiles may have asked for it)
     p.nsplit = 1;
 #define H2_M16(SP_, WM_, UP_)                                                                                   \
