@@ -686,12 +686,14 @@ static void gn_launch(const GnP& p, hipStream_t s) {
       hipLaunchKernelGGL(groupnorm_bwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
     else
       hipLaunchKernelGGL(groupnorm_fwd_kernel, grid, dim3(64 * GN_WAVES), 0, s, p);
-  } else if (!BWD && n <= 128 && groups >= 16384 && !(getenv("I2R_GN_SMALL") && getenv("I2R_GN_SMALL")[0] == '0')) {
+  } else if (!BWD && n <= 256 && groups >= 16384 && !(getenv("I2R_GN_SMALL") && getenv("I2R_GN_SMALL")[0] == '0')) {
     // many small groups: four groups per lane slot, their loads in flight together
     if (n <= 64)
       hipLaunchKernelGGL((gn_fwd_small_kernel<16, 4>), dim3(i2r_cdiv(groups, 4 * 16)), dim3(256), 0, s, p);
-    else
+    else if (n <= 128)
       hipLaunchKernelGGL((gn_fwd_small_kernel<32, 4>), dim3(i2r_cdiv(groups, 4 * 8)), dim3(256), 0, s, p);
+    else   // (256 elements: 8x8 x 4 channels, shape A's top level; the decoder concats of the 4x4 level)
+      hipLaunchKernelGGL((gn_fwd_small_kernel<64, 4>), dim3(i2r_cdiv(groups, 4 * 4)), dim3(256), 0, s, p);
   } else if (n <= 64) {
     GN_GO(16, 1);
   } else if (n <= 128) {

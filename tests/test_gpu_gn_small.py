@@ -15,9 +15,10 @@ from tests.helpers import assert_close
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# (batch, channels, image side): groups of 16 / 32 / 64 / 128 elements, >= 16384 of them; 513 and 700 leave a ragged
+# (batch, channels, image side): groups of 16 / 32 / 64 / 128 / 256 elements, >= 16384 of them; 513 and 700 leave a ragged
 # last slot (group count not a multiple of the 4 groups a lane slot walks, nor of a workgroup's 32 / 64)
-SHAPES = [(512, 128, 2), (513, 256, 2), (512, 512, 2), (600, 1024, 2), (700, 128, 4), (512, 256, 4), (1024, 128, 2)]
+SHAPES = [(512, 128, 2), (513, 256, 2), (512, 512, 2), (600, 1024, 2), (700, 128, 4), (512, 256, 4), (1024, 128, 2),
+          (513, 128, 8), (600, 512, 4)]   # 256 elements per group: the 64-lane slots
 
 
 def _small_off():
@@ -46,7 +47,7 @@ def _ref(x, w, b, ss, act):
 def test_small_group_forward_all_fused_modes(B, C, H):
     from imageni2r_amd import ops
     n = C // 32 * H * H
-    assert n <= 128 and B * 32 >= 16384  # the dispatch condition of gn_launch<false>
+    assert n <= 256 and B * 32 >= 16384  # the dispatch condition of gn_launch<false>
     g = torch.Generator().manual_seed(B + C + H)
     x = torch.randn(B, C, H, H, generator=g) * 1.7 + 0.4
     w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
@@ -72,12 +73,13 @@ def test_small_group_forward_all_fused_modes(B, C, H):
     assert_close(rstd.cpu().numpy(), (1.0 / torch.sqrt(xm.var(2, unbiased=False) + 1e-5)).reshape(-1).numpy(), 1e-5)
 
 
-@pytest.mark.parametrize("B,C1,C2,H", [(512, 512, 512, 2), (520, 256, 256, 2), (512, 256, 128, 2), (512, 128, 128, 4)])
+@pytest.mark.parametrize("B,C1,C2,H", [(512, 512, 512, 2), (520, 256, 256, 2), (512, 256, 128, 2), (512, 128, 128, 4),
+                                       (520, 256, 256, 4), (512, 256, 128, 4)])
 def test_small_group_forward_over_the_decoder_concat(B, C1, C2, H):
     """norm0 of a decoder block reads torch.cat([x, skip], 1) in place (networks.py:458 -> :168)."""
     from imageni2r_amd import ops
     C = C1 + C2
-    assert C // 32 * H * H <= 128
+    assert C // 32 * H * H <= 256
     g = torch.Generator().manual_seed(C1 + C2 + H)
     x1, x2 = torch.randn(B, C1, H, H, generator=g), torch.randn(B, C2, H, H, generator=g) * 3 - 1
     w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)

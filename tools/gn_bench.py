@@ -22,7 +22,7 @@ ap.add_argument("--acc", action="store_true")
 ap.add_argument("--add", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
-for (C, H) in [(128, 16), (256, 16), (384, 16), (256, 8), (512, 8), (256, 4), (512, 2), (1024, 2)]:
+for (C, H) in [(128, 16), (256, 16), (384, 16), (256, 8), (512, 8), (256, 4), (512, 2), (1024, 2), (128, 8), (512, 4)]:
     B = a.batch
     x = torch.randn(B, C, H, H, device=dev)
     w, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
