@@ -48,6 +48,7 @@ struct ConvHParams {
                           // inputs are multiplied by s before the f16 split and the result by 1/s -- both exact -- so
                           // that tensors far below fp16's normal range (gradients: the data-gradient use of this
                           // kernel, i2r_conv2d_dgrad_h2) keep their 22 significand bits
+  int hw1_vec; // 1 (1x1 conv on 1x1 images, 16-byte-aligned rows): the tiled kernel fetches a position's channels with 16-byte loads
   int qkv_out; // 1: the output feeds i2r_attention_fwd_h2(presplit): q channels (c % 3 == 0) are scaled by I2R_QSCALE and
                // every element is stored as the split pair f16 hi | f16 lo << 16 (the attention kernel then only permutes)
 };
@@ -411,6 +412,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
 
   uint4v ra[NA];
   float rb[NRAW][8];
+  // (1x1 convs on 1x1 images with 16-byte-aligned operands and Cin splits: see load_b)
+  const bool hw1 = KS == 1 && p.HW == 1 && p.hw1_vec;
   // live = false (a chunk past this workgroup's range): the scalar offset is pushed out of the buffer, so the loads
   // return 0 without touching memory -- keeps the main loop branch-free
   auto load_a = [&](int c, bool live) {
@@ -434,6 +437,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fwd_h2_kernel(ConvHParams p) 
         unsigned sB = (unsigned)(cb * 16 + j) * chan_bytes + dead;
 #pragma unroll
         for (int s = 0; s < NRAW; ++s) rb[s][j] = bufload(rB, voffB[s], sB);
+      }
+    } else if (hw1) {
+      // 1x1 images: a position's channels are CONSECUTIVE floats, so the lane's eight channels of a k-step are two
+      // 16-byte loads instead of eight dword loads that each touch 64 different cache lines across the wave (the
+      // bottom level of the 8x8-image nets: 40 us per launch for 6 MB of operands)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cbase = c * 64 + q * 16;
+        const bool first = cbase < p.Cin1;  // wave-uniform
+        const unsigned sB = (unsigned)(first ? cbase : cbase - p.Cin1) * 4u + dead;
+        const uint4v lo4 = bufload4(first ? rB : rB2, first ? voffB[0] : voffB2, sB);
+        const uint4v hi4 = bufload4(first ? rB : rB2, first ? voffB[0] : voffB2, sB + 16u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          rb[q][j] = __builtin_bit_cast(float, (unsigned)lo4[j]);
+          rb[q][4 + j] = __builtin_bit_cast(float, (unsigned)hi4[j]);
+        }
       }
     } else {
 #pragma unroll
@@ -1779,6 +1799,8 @@ static int h2_launch(const float* x, const float* x2, int Cin1, const void* wp, 
   p.Npos = Npos; p.chunks_per_split = cps; p.nsplit = nsplit; p.slab_stride = Npos * Cout;
   { const char* ab = getenv("I2R_H2_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   p.qkv_out = qkv_out; p.up_in = up_in; p.up_res = up_res;
+  p.hw1_vec = ksize == 1 && H * W == 1 && (Cin1 & 3) == 0 && ((Cin - Cin1) & 3) == 0 &&
+              ((((uintptr_t)x) | ((uintptr_t)(x2 ? x2 : x))) & 15) == 0 && !getenv("I2R_H2_HW1_SCALAR");
   p.in_scale = in_scale;  // (null on every forward call: the un-split path then multiplies by exactly 1)
   hipStream_t s = (hipStream_t)stream;
   p.mtiles = i2r_cdiv(Cout, 128);

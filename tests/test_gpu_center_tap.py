@@ -65,3 +65,49 @@ def test_center_tap_conv_on_1x1_images(tap_env, B, Cin, Cout, down, split, has_r
         y2 = layer(xin, residual=None, x_split=split)
         ref2 = torch.nn.functional.conv2d(xv, layer.weight.double(), layer.bias.double(), padding=1)
         assert float((y2.double() - ref2).abs().max() / ref2.abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cin2,Cout,split,has_res", [(2048, 256, 0, 256, True, True), (4096, 512, 0, 768, True, False),
+                                                        (130, 256, 256, 256, False, False), (7, 72, 0, 40, False, True),
+                                                        (1000, 256, 128, 256, False, False), (2048, 100, 0, 64, False, False)])
+def test_1x1_conv_on_1x1_images_vector_loads(B, Cin, Cin2, Cout, split, has_res):
+    """On 1x1 images a position's channels are consecutive floats: the tiled 1x1 kernel fetches them with 16-byte
+    loads.  Same bits as with dword loads (I2R_H2_HW1_SCALAR=1), fp32-grade against fp64; channel counts that do not fill
+    the last 64-channel chunk, a channel concat (both sources), pair-format input, residual."""
+    from imageni2r_amd import ops
+    import imageni2r_amd
+    imageni2r_amd.set_conv_math("f16x2")
+    gen = torch.Generator().manual_seed(B + Cin + Cout)
+    Ct = Cin + Cin2
+    x = (torch.randn(B, Ct, 1, 1, generator=gen) * 1.5 + 0.3).to(DEV)
+    w = (torch.randn(Cout, Ct, 1, 1, generator=gen) / np.sqrt(Ct)).to(DEV)
+    b = torch.randn(Cout, generator=gen).to(DEV)
+    res = torch.randn(B, Cout, 1, 1, generator=gen).to(DEV) if has_res else None
+    xin, xv = x, x.double()
+    if split:
+        xin, _, _ = ops.groupnorm_fwd(x, torch.ones(Ct, device=DEV), torch.zeros(Ct, device=DEV), 32, 1e-5, act=True,
+                                      split_out=True)
+        words = xin.view(torch.int32)
+        xv = ((words & 0xFFFF).to(torch.int16).view(torch.float16).double()
+              + ((words >> 16) & 0xFFFF).to(torch.int16).view(torch.float16).double())
+    wp = ops.conv2d_pack_h2(w)
+
+    def run():
+        if Cin2:
+            return ops.conv1x1_cat_fwd_h2(xin[:, :Cin].contiguous(), xin[:, Cin:].contiguous(), tuple(w.shape), wp, b, res)
+        return ops.conv2d_fwd_h2(xin, tuple(w.shape), wp, b, res, x_split=split)
+
+    prev = os.environ.pop("I2R_H2_HW1_SCALAR", None)
+    try:
+        y = run()
+        os.environ["I2R_H2_HW1_SCALAR"] = "1"
+        y_scalar = run()
+    finally:
+        os.environ.pop("I2R_H2_HW1_SCALAR", None)
+        if prev is not None:
+            os.environ["I2R_H2_HW1_SCALAR"] = prev
+    ref = torch.einsum("oc,bchw->bohw", w[:, :, 0, 0].double(), xv) + b.double().view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + res.double()
+    assert torch.equal(y, y_scalar)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 5e-6
