@@ -24,11 +24,52 @@ gen = torch.Generator(device=dev).manual_seed(5)
 xT = torch.randn(batch, args.input_channels, S, S, device=dev, generator=gen)
 proc = DiffusionProcess(args, model.net, (args.input_channels, S, S))
 noise = os.environ.get("DET_NOISE") == "1"   # an unrelated stream kept busy beside the sampler (matmuls + copies)
+own = os.environ.get("DET_OWN", "")          # ... or with ONE family of this library's kernels: gn | conv3 | conv1 | attn
+from imageni2r_amd import ops  # noqa: E402
+if own:
+    gq = torch.Generator(device=dev).manual_seed(9)
+    ox = torch.randn(2048, 128, 16, 16, device=dev, generator=gq)
+    og, ob = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    oxs, _, _ = ops.groupnorm_fwd(ox, og, ob, 32, 1e-5, act=True, split_out=True)
+    ow3 = ops.conv2d_pack_h2(torch.randn(128, 128, 3, 3, device=dev, generator=gq) * 0.03)
+    ow1 = ops.conv2d_pack_h2(torch.randn(384, 128, 1, 1, device=dev, generator=gq) * 0.09)
+    oqkv = torch.randn(2048, 384, 16, 16, device=dev, generator=gq)
 ns = torch.cuda.Stream(device=dev)
 na, nb = torch.randn(4096, 4096, device=dev), torch.randn(1 << 26, device=dev)
 
 
+eager2 = os.environ.get("DET_EAGER2") == "1"   # the two halves EAGERLY (no graphs) on two streams
+if eager2:
+    pe = DiffusionProcess(args, model.net, (args.input_channels, S, S), use_graph=False)
+    pe.range_check = False
+    s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+
 def sample_once():
+    if eager2:
+        halves = xT.chunk(2)
+        res = []
+        cur = torch.cuda.current_stream()
+        for st, h in zip(s2, halves):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                res.append(pe.sample(h))
+        for st in s2:
+            cur.wait_stream(st)
+        torch.cuda.synchronize()
+        return torch.cat(res).clone()
+    if own:
+        ns.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ns):
+            for _ in range({"gn": 9000, "conv3": 1600, "conv1": 5000, "attn": 4000}[own]):
+                if own == "gn":
+                    ops.groupnorm_fwd(ox, og, ob, 32, 1e-5, act=True, split_out=True)
+                elif own == "conv3":
+                    ops.conv2d_fwd_h2(oxs, (128, 128, 3, 3), ow3, None, ox, x_split=True)
+                elif own == "conv1":
+                    ops.conv2d_fwd_h2(oxs, (384, 128, 1, 1), ow1, None, None, x_split=True, qkv_out=True)
+                else:
+                    ops.attention_fwd(oqkv, 2)
     if noise:
         ns.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ns):
