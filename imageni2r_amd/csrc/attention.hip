@@ -174,6 +174,13 @@ __device__ __forceinline__ void attn_small_vec(const float* __restrict__ base, f
       for (int j = 0; j < 4; ++j) acc[j] += p4[j] * v;
     }
     *reinterpret_cast<f4*>(ob + c * T + qi) = acc;
+    // In the fully unrolled form the next item's `acc = 0` lands in the SAME registers right behind this 16-byte
+    // store, and on gfx950 nothing keeps a VALU write away from the data registers of a store that has been issued
+    // but has not read them yet (the trap of the f16x2 conv epilogues): alone the kernel was always
+    // right; with the vector-memory path backed up by another stream's attention kernel on the same CU, 22 of 8192
+    // workgroups stored zeros / the next item's partial sums (tools/r3_det_victim3.py) -- and the two-stream sampler
+    // stopped being reproducible.  Two wait states tied to the data registers.
+    asm volatile("s_nop 1" : "+v"(acc) : : "memory");
   }
 }
 

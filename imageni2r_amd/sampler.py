@@ -48,13 +48,11 @@ class DiffusionProcess:
         # at every evaluation, and with the pointer-swapped ema_scope the weights it sees sit at the same addresses
         # each time, so the second evaluation replays the first one's graphs
         self._graphs = self.net.__dict__.setdefault("_i2r_sampler_graphs", {})
-        # Two concurrent half-batch graphs on two streams (+1-2 % series/s) are OFF by default (0): replayed side by
-        # side the two graphs are not bit-reproducible -- the first ~200 series of each half differ from run to run by
-        # up to 1e-4 of the largest value (tools/r3_determinism_check.py; one graph alone, even beside an unrelated busy
-        # stream, repeats to the bit).  I2R_DUAL_STREAM_MIN=2048 (the default of rounds 1-3 until this was found)
-        # switches the form on for batches of at least that many series, or of as many positions as that many 16x16
-        # images have.
-        self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 0))
+        # batches at least this big (or of as many positions as that many 16x16 images) are sampled as two concurrent
+        # half-batch graphs on two streams (0: off).  Replays are bit-reproducible in both forms
+        # (tests/test_gpu_bench_batch.py; tools/r3_determinism_check.py -- which is how a store-data hazard in the small
+        # attention kernel was found: it only showed beside another stream's kernels).
+        self.dual_stream_min = int(os.environ.get("I2R_DUAL_STREAM_MIN", 2048))
         self._streams = None
         # fp16 range guard of the f16x2 kernels (DESIGN.md "range contract"): series that come back non-finite are
         # sampled again on the exact fp32 kernels.  One isfinite reduction + host sync per sample() call; 0 = off.

@@ -35,3 +35,28 @@ def test_small_attention_against_fp64(B, heads, H, W):
     err_lse = float((lse.double().view(B * heads, T) - torch.logsumexp(s, dim=-1).reshape(B * heads, T)).abs().max())
     assert err < 2e-6, err
     assert err_lse < 1e-5, err_lse
+
+
+def test_small_attention_is_reproducible_beside_another_streams_kernels():
+    """The T = 16 form is fully unrolled; the next item's accumulator clear sat right behind a 16-byte store of the same
+    registers, and on gfx950 nothing keeps a VALU write away from the data of a store that is issued but has not read
+    its registers yet.  Alone the kernel was always right; with the vector-memory path backed up by another stream's
+    f16x2 attention launches on the same CUs a few workgroups in a thousand stored other values (errors of order 1) --
+    which made the two-stream sampler irreproducible.  Same bits beside the loop as alone, for every token count."""
+    from imageni2r_amd import ops
+    import imageni2r_amd
+    imageni2r_amd.set_conv_math("f16x2")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    noise = torch.randn(2048, 384, 16, 16, device=DEV, generator=g)
+    side = torch.cuda.Stream()
+    for (H, W, heads, lse) in ((4, 4, 4, False), (4, 4, 4, True), (2, 4, 4, False), (2, 2, 8, False), (3, 3, 4, False)):
+        x = torch.randn(2048, 192 * heads, H, W, device=DEV, generator=g)
+        ref = ops.attention_fwd(x, heads, save_lse=lse)[0].clone()
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                ops.attention_fwd(noise, 2)
+        outs = [ops.attention_fwd(x, heads, save_lse=lse)[0] for _ in range(6)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs), (H, W, heads, lse)
