@@ -26,8 +26,11 @@ def conv_case(name, Cin, Cout, H, k):
     dy = R(B, Cout, H, H)
     wp = ops.conv2d_pack(w)
     cands[f"conv fwd f32 {name}"] = lambda: ops.conv2d_fwd(x, w, b, None, wp)
-    cands[f"conv dgrad f32 {name}"] = lambda: ops.conv2d_dgrad(dy, w, tuple(x.shape))
-    cands[f"conv wgrad (det) {name}"] = lambda: ops.conv2d_wgrad(x, dy, tuple(w.shape), True)[0]
+    cands[f"conv dgrad f32 {name}"] = lambda: ops.conv2d_dgrad(dy, w)
+    cands[f"conv wgrad (det) {name}"] = lambda: ops.conv2d_wgrad(x, dy, k, True)[0]
+    if H >= 8:   # the f16x2 data gradient of the high-resolution levels
+        wpd = ops.conv2d_pack_h2_dgrad(w)
+        cands[f"conv dgrad f16x2 {name}"] = lambda: ops.conv2d_dgrad_h2(dy, tuple(w.shape), wpd)
 
 
 for (name, Cin, Cout, H, k) in (("128->128 3x3 @16", 128, 128, 16, 3), ("256->256 3x3 @8", 256, 256, 8, 3), ("512->512 3x3 @2", 512, 512, 2, 3),
@@ -48,7 +51,9 @@ for (heads, H) in ((2, 16), (4, 8), (4, 4), (8, 2)):
     cands[f"attention fwd+lse h{heads}@{H}"] = (lambda qkv=qkv, heads=heads: ops.attention_fwd(qkv, heads, save_lse=True)[0])
     cands[f"attention bwd h{heads}@{H}"] = (lambda qkv=qkv, a=a, lse=lse, da=da, heads=heads: ops.attention_bwd(qkv, a, lse, da, heads))
 xl, wl, bl = R(B, 512), R(2048, 512) / 22.0, R(2048)
-cands["linear fwd 512->2048"] = lambda: ops.linear_fwd(xl, wl, bl, act=True)
+cands["linear fwd 512->2048"] = lambda: ops.linear_fwd(xl, wl, bl, act=True)[0]
+dyl = R(B, 2048)
+cands["linear bwd dx 512->2048"] = lambda: ops.linear_bwd(xl, wl, dyl, need_dw=False)[0]
 
 torch.cuda.synchronize()
 for name, fn in cands.items():
